@@ -1,0 +1,232 @@
+/*
+ * mpsfm_hip.h — C ABI of libmpsfm_hip.so, the MI355X (gfx950) replacement for the
+ * pyceres / pycolmap native boundary that MP-SfM's bundle adjustment and triangulation
+ * numerics cross (reference call sites cited per entry point below; paths are relative
+ * to the reference checkout).
+ *
+ * Conventions
+ *   - Plain C, no exceptions, no torch types.  Every entry point returns 0 on success or a
+ *     negative MPSFM_E* code; mpsfm_last_error() gives a thread-local message.
+ *   - The caller owns every buffer.  The library never retains a host pointer after a call
+ *     returns (handles own device copies only).
+ *   - All floating point is IEEE double.  Indices are int32 (counts int64).
+ *   - Quaternions are stored (x, y, z, w) — Eigen order — as in
+ *     mpsfm/sfm/mapper/bundle_adjustment.py:113-122 (pose.rotation.quat).
+ *   - The library fails loudly (MPSFM_ENODEVICE) when no gfx950 device is present; there is
+ *     no CPU fallback inside it.
+ */
+#ifndef MPSFM_HIP_H
+#define MPSFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPSFM_ABI_VERSION 1
+
+/* ---- error codes -------------------------------------------------------------------- */
+#define MPSFM_OK 0
+#define MPSFM_EINVAL (-1)     /* malformed problem (index out of range, NULL pointer, ...) */
+#define MPSFM_ENODEVICE (-2)  /* no HIP device / not gfx950 */
+#define MPSFM_ENOMEM (-3)     /* host or device allocation failed */
+#define MPSFM_EHIP (-4)       /* a HIP runtime call failed */
+#define MPSFM_ENUMERIC (-5)   /* the initial point could not be evaluated (NaN / z<=0 in a log) */
+#define MPSFM_EUNSUPPORTED (-6)
+#define MPSFM_ECOMM (-7)      /* the all-reduce hook reported a failure */
+
+/* ---- loss functions ------------------------------------------------------------------
+ * pycolmap.LossFunctionType as mapped in mpsfm/sfm/mapper/bundle_adjustment.py:44-48.
+ * rho(s), s = squared residual norm (Ceres semantics):
+ *   TRIVIAL  rho = s
+ *   SOFT_L1  rho = 2 a^2 (sqrt(1 + s/a^2) - 1)
+ *   CAUCHY   rho = a^2 log(1 + s/a^2)
+ * Every loss is wrapped as Scaled(rho, magnitude): cost = 1/2 * magnitude * rho(s).      */
+enum mpsfm_loss_type { MPSFM_LOSS_TRIVIAL = 0, MPSFM_LOSS_SOFT_L1 = 1, MPSFM_LOSS_CAUCHY = 2 };
+
+/* ---- the flat BA problem -------------------------------------------------------------
+ * Exactly what Optimizer.__build_problem (bundle_adjustment.py:67-185) gathers before it
+ * calls pyceres.solve: the images of the bundle (with gauge flags), the 3-D points their
+ * observations reference, one 2-residual PINHOLE reprojection block per observation
+ * (pycolmap.create_default_bundle_adjuster, :85-104) and one 1-residual log-depth block per
+ * valid depth prior (pycolmap.create_depth_bundle_adjuster, :163-176).                   */
+typedef struct mpsfm_ba_problem {
+  int32_t n_cams;  /* images (poses) referenced by the observation lists            */
+  int32_t n_pts;   /* 3-D points                                                      */
+  int32_t n_intr;  /* distinct PINHOLE intrinsics                                     */
+
+  const double* cam_intr;        /* [n_intr][4]  fx fy cx cy; constant (:92-94)      */
+  const int32_t* cam_intr_idx;   /* [n_cams]                                          */
+  const uint8_t* pose_const;     /* [n_cams] 1: quat and translation constant
+                                    (first bundle image :114-116, fix_pose, or an image
+                                    outside the bundle that sees a variable point)     */
+  int32_t gauge_axis_cam;        /* camera whose translation x is held fixed
+                                    (SubsetManifold(3,[0]), :117-121), or -1           */
+  const uint8_t* pt_const;       /* [n_pts] 1: point constant                          */
+
+  int64_t n_obs;                 /* reprojection residual blocks                        */
+  const int32_t* obs_cam;        /* [n_obs]                                             */
+  const int32_t* obs_pt;         /* [n_obs]                                             */
+  const double* obs_xy;          /* [n_obs][2] pixel measurement (Point2D.xy)           */
+  int32_t reproj_loss_type;      /* mpsfm_loss_type (reference default SOFT_L1, :24)    */
+  double reproj_loss_scale;      /* a  = reproj_loss_scale * kp_std (:101)              */
+  double reproj_loss_magnitude;  /* k  = 1 / kp_std^2 (:99)                             */
+
+  int64_t n_dobs;                /* log-depth residual blocks (0: reprojection only)    */
+  const int32_t* dobs_cam;       /* [n_dobs]                                            */
+  const int32_t* dobs_pt;        /* [n_dobs]                                            */
+  const double* dobs_depth;      /* [n_dobs] prior depth d sampled at the keypoint      */
+  const double* dobs_magnitude;  /* [n_dobs] m = d^2 / clip(var,1e-6) (:161)            */
+  const double* dobs_param;      /* [n_dobs] a = mult * rob_std * sqrt(var) / d (:160)  */
+  int32_t depth_loss_type;       /* CAUCHY in ba(), TRIVIAL in refine_3d_points()       */
+  const double* shift_logscale;  /* [n_cams][2] constant per-image (shift b, log-scale s)
+                                    of the prior, NULL = zeros (:83, :178-182)          */
+} mpsfm_ba_problem;
+
+/* Parameters the solver updates in place, like Ceres does through the pybind11 views. */
+typedef struct mpsfm_ba_state {
+  double* cam_quat_xyzw; /* [n_cams][4] */
+  double* cam_t;         /* [n_cams][3] */
+  double* pts;           /* [n_pts][3]  */
+} mpsfm_ba_state;
+
+/* Sum-all-reduce hook for landmark-sharded BA: called with a buffer of `count` doubles that
+ * must be replaced by its element-wise sum over all ranks before the hook returns (or, for a
+ * device buffer, before later work on `stream`).  `on_device` is 1 when `buf` is device
+ * memory of the handle's device.  Return 0 on success. */
+typedef int (*mpsfm_allreduce_fn)(void* user, double* buf, int64_t count, int on_device,
+                                  void* stream);
+
+/* Solver options.  mpsfm_ba_default_options() fills the pyceres.SolverOptions() defaults
+ * that Optimizer.solve leaves untouched (bundle_adjustment.py:285-293). */
+typedef struct mpsfm_ba_options {
+  int32_t max_num_iterations;               /* 50    */
+  double function_tolerance;                /* 1e-6  */
+  double gradient_tolerance;                /* 1e-10 */
+  double parameter_tolerance;               /* 1e-8  */
+  double initial_trust_region_radius;       /* 1e4   */
+  double max_trust_region_radius;           /* 1e16  */
+  double min_trust_region_radius;           /* 1e-32 */
+  double min_relative_decrease;             /* 1e-3  */
+  double min_lm_diagonal;                   /* 1e-6  */
+  double max_lm_diagonal;                   /* 1e32  */
+  int32_t max_num_consecutive_invalid_steps;/* 5     */
+  int32_t jacobi_scaling;                   /* 1     */
+  int32_t device;                           /* HIP device ordinal                      */
+  void* stream;                             /* hipStream_t to run on, NULL = own stream */
+  int32_t verbose;                          /* >0: per-iteration line on stderr         */
+  mpsfm_allreduce_fn allreduce;             /* NULL: single shard                       */
+  void* allreduce_user;
+} mpsfm_ba_options;
+
+#define MPSFM_MAX_TRACE 64
+
+enum mpsfm_termination {
+  MPSFM_TERM_FUNCTION_TOLERANCE = 0,
+  MPSFM_TERM_GRADIENT_TOLERANCE = 1,
+  MPSFM_TERM_PARAMETER_TOLERANCE = 2,
+  MPSFM_TERM_MAX_ITERATIONS = 3,
+  MPSFM_TERM_MIN_RADIUS = 4,
+  MPSFM_TERM_INVALID_STEPS = 5, /* Ceres FAILURE: too many consecutive invalid steps */
+  MPSFM_TERM_NO_VARIABLES = 6
+};
+
+typedef struct mpsfm_ba_summary {
+  double initial_cost;       /* includes fixed_cost */
+  double final_cost;         /* includes fixed_cost */
+  double fixed_cost;         /* blocks whose camera and point are both constant */
+  int32_t num_iterations;    /* LM iterations performed (iteration 0 not counted) */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t termination;       /* mpsfm_termination */
+  int64_t num_residual_blocks;   /* reprojection + depth blocks in the problem   */
+  int64_t num_residual_evals;    /* residual blocks x (cost or Jacobian) evaluations */
+  int64_t num_jacobian_evals;    /* Jacobian sweeps */
+  int32_t reduced_dim;       /* order of the reduced camera system */
+  double final_radius;
+  double time_total_s;       /* wall time of the solve, device-synchronised */
+  double time_linearize_s;   /* device time: track sweep (residual/Jacobian/Schur reduce) */
+  double time_dense_s;       /* device time: reduced camera system factor + solve          */
+  double time_update_s;      /* device time: back-substitution + candidate cost sweep      */
+  int32_t trace_len;
+  double trace_cost[MPSFM_MAX_TRACE];     /* cost after each iteration (index 0 = initial)  */
+  double trace_radius[MPSFM_MAX_TRACE];
+  uint8_t trace_accepted[MPSFM_MAX_TRACE];
+} mpsfm_ba_summary;
+
+typedef struct mpsfm_ba_handle mpsfm_ba_handle;
+
+/* -- library ------------------------------------------------------------------------- */
+int mpsfm_abi_version(void);
+const char* mpsfm_last_error(void);
+/* number of visible gfx950 devices (0 on a CPU-only host; does not initialise a context) */
+int mpsfm_device_count(void);
+void mpsfm_ba_default_options(mpsfm_ba_options* opt);
+
+/* -- bundle adjustment: replaces pyceres.solve(options, bundler.problem, summary)
+ *    (bundle_adjustment.py:184, 285-293) ---------------------------------------------- */
+
+/* One-shot: upload, solve, write the refined poses/points back into `state`. */
+int mpsfm_ba_solve(const mpsfm_ba_problem* problem, mpsfm_ba_state* state,
+                   const mpsfm_ba_options* options, mpsfm_ba_summary* summary);
+
+/* Resident form: the problem lives in HBM between calls (what bench.py times). */
+int mpsfm_ba_create(const mpsfm_ba_problem* problem, const mpsfm_ba_state* initial,
+                    const mpsfm_ba_options* options, mpsfm_ba_handle** out);
+int mpsfm_ba_set_state(mpsfm_ba_handle* h, const mpsfm_ba_state* state); /* H2D            */
+int mpsfm_ba_reset_state(mpsfm_ba_handle* h);  /* D2D: back to the state given at create   */
+int mpsfm_ba_solve_resident(mpsfm_ba_handle* h, mpsfm_ba_summary* summary);
+int mpsfm_ba_get_state(mpsfm_ba_handle* h, mpsfm_ba_state* state);       /* D2H            */
+void mpsfm_ba_destroy(mpsfm_ba_handle* h);
+
+/* Cost of the current resident state: 1/2 sum rho, split by block kind. */
+int mpsfm_ba_eval_cost(mpsfm_ba_handle* h, double* cost_reproj, double* cost_depth);
+
+/* One Jacobian/Schur track sweep at the current state with trust-region radius `radius`
+ * (no parameter update): the kernel bench.py prices against the HBM roofline.
+ * `elapsed_ms` receives the HIP-event time of that kernel alone. */
+int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms);
+/* Download the reduced camera system built by the last sweep: S (n x n, row-major, symmetric)
+ * and rhs (n); n = summary.reduced_dim.  Test/diagnostic entry point. */
+int mpsfm_ba_get_reduced_system(mpsfm_ba_handle* h, double* S, double* rhs, int32_t n);
+int mpsfm_ba_reduced_dim(mpsfm_ba_handle* h);
+/* Factor + solve only, on the last assembled system (prices the MFMA dense solve). */
+int mpsfm_ba_dense_solve_once(mpsfm_ba_handle* h, float* elapsed_ms);
+
+/* -- point covariances: replaces pycolmap.estimate_ba_covariance(POINTS)
+ *    (bundle_adjustment.py:244-261).  cov[j] = (sum_i magnitude * Jp_i^T Jp_i)^-1 over the
+ *    reprojection blocks of point j with every other variable held constant. ------------- */
+int mpsfm_point_covs(const mpsfm_ba_problem* problem, const mpsfm_ba_state* state,
+                     int32_t device, double* covs /* [n_pts][3][3] */);
+
+/* -- per-track triangulation numerics: the arithmetic inside
+ *    pycolmap.IncrementalTriangulator / ObservationManager used at
+ *    mpsfm/sfm/mapper/triangulator.py:48,53-55,123-128 and mapper/base.py:686-797 -------- */
+typedef struct mpsfm_tracks {
+  int32_t n_cams, n_tracks, n_intr;
+  const double* cam_quat_xyzw; /* [n_cams][4] */
+  const double* cam_t;         /* [n_cams][3] */
+  const double* cam_intr;      /* [n_intr][4] */
+  const int32_t* cam_intr_idx; /* [n_cams]    */
+  const int64_t* track_start;  /* [n_tracks+1] CSR offsets into the element arrays */
+  const int32_t* el_cam;       /* [n_el] */
+  const double* el_xy;         /* [n_el][2] */
+} mpsfm_tracks;
+
+/* Linear multi-view triangulation of every track (COLMAP TriangulateMultiViewPoint):
+ * xyz[t] = smallest eigenvector of sum_i (P_i - x_i x_i^T P_i)^T (...), dehomogenised. */
+int mpsfm_triangulate_tracks(const mpsfm_tracks* tracks, int32_t device,
+                             double* xyz /* [n_tracks][3] out */);
+
+/* Per-track quality numbers at given points: max pairwise triangulation angle (radians),
+ * per-element squared reprojection error and cheirality (depth > 0) flags.
+ * Any output pointer may be NULL. */
+int mpsfm_filter_tracks(const mpsfm_tracks* tracks, const double* xyz /* [n_tracks][3] */,
+                        int32_t device, double* max_tri_angle /* [n_tracks] */,
+                        double* el_sq_err /* [n_el] */, uint8_t* el_front /* [n_el] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPSFM_HIP_H */

@@ -1,0 +1,217 @@
+"""Seeded synthetic bundle-adjustment scenes.
+
+Cameras on a jittered orbit of radius 10 looking at the centre of a 6x6x4 box of uniform
+landmarks; one shared PINHOLE camera (fx=fy=1200, cx=800, cy=600, 1600x1200).  Track length
+k = clip(2 + Poisson(3), 2, min(30, Nc)); the k cameras nearest in azimuth that see the point.
+Measurements = projection + N(0,1) px noise, 5 % outliers U(-20,20) px, rounded to float16 and
+widened to float64 (mirrors reference mpsfm/sfm/scene/correspondences/base.py:123).  Depth
+priors follow the reference's variance model (mpsfm/sfm/scene/image/depth.py:15,28,77-103) and
+the weights of bundle_adjustment.py:153-161.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .problem import LOSS_CAUCHY, LOSS_SOFT_L1, BAProblem
+
+CONFIGS = {
+    # name: (n_cams, n_pts, with_depth)
+    "tiny": (6, 300, True),
+    "C2": (50, 20_000, False),
+    "C3": (200, 150_000, True),
+    "C4": (1000, 800_000, True),
+}
+
+FX = FY = 1200.0
+CX, CY = 800.0, 600.0
+WIDTH, HEIGHT = 1600.0, 1200.0
+
+
+def quat_from_R(R: np.ndarray) -> np.ndarray:
+    """Rotation matrices [N,3,3] -> unit quaternions [N,4] in (x,y,z,w) order."""
+    R = np.asarray(R, dtype=np.float64).reshape(-1, 3, 3)
+    q = np.empty((R.shape[0], 4))
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    for i in range(R.shape[0]):
+        m = R[i]
+        if tr[i] > 0:
+            s = np.sqrt(tr[i] + 1.0) * 2
+            q[i] = [(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s]
+        elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+            s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+            q[i] = [0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s, (m[2, 1] - m[1, 2]) / s]
+        elif m[1, 1] > m[2, 2]:
+            s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+            q[i] = [(m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s, (m[0, 2] - m[2, 0]) / s]
+        else:
+            s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+            q[i] = [(m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s, (m[1, 0] - m[0, 1]) / s]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q
+
+
+def R_from_quat(q: np.ndarray) -> np.ndarray:
+    """Unit quaternions [N,4] (x,y,z,w) -> rotation matrices [N,3,3]."""
+    q = np.asarray(q, dtype=np.float64).reshape(-1, 4)
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((q.shape[0], 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z)
+    R[:, 0, 1] = 2 * (x * y - z * w)
+    R[:, 0, 2] = 2 * (x * z + y * w)
+    R[:, 1, 0] = 2 * (x * y + z * w)
+    R[:, 1, 1] = 1 - 2 * (x * x + z * z)
+    R[:, 1, 2] = 2 * (y * z - x * w)
+    R[:, 2, 0] = 2 * (x * z - y * w)
+    R[:, 2, 1] = 2 * (y * z + x * w)
+    R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def quat_mul(p: np.ndarray, q: np.ndarray) -> np.ndarray:
+    px, py, pz, pw = p[..., 0], p[..., 1], p[..., 2], p[..., 3]
+    qx, qy, qz, qw = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack(
+        [
+            pw * qx + px * qw + py * qz - pz * qy,
+            pw * qy - px * qz + py * qw + pz * qx,
+            pw * qz + px * qy - py * qx + pz * qw,
+            pw * qw - px * qx - py * qy - pz * qz,
+        ],
+        axis=-1,
+    )
+
+
+def _orbit_cameras(rng, n_cams):
+    az = np.sort(rng.uniform(0.0, 2 * np.pi, n_cams)) if n_cams > 2 else np.array([0.0, 0.35, 0.7][:n_cams])
+    radius = 10.0 + rng.normal(0.0, 0.3, n_cams)
+    height = rng.normal(0.0, 0.8, n_cams)
+    centers = np.stack([radius * np.cos(az), radius * np.sin(az), height], axis=1)
+    target = rng.normal(0.0, 0.2, (n_cams, 3))
+    fwd = target - centers
+    fwd /= np.linalg.norm(fwd, axis=1, keepdims=True)
+    up = np.array([0.0, 0.0, 1.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right, axis=1, keepdims=True)
+    down = np.cross(fwd, right)
+    R = np.stack([right, down, fwd], axis=1)  # rows: camera x, y, z axes in world
+    t = -np.einsum("nij,nj->ni", R, centers)
+    return R, t, az
+
+
+def make_scene(
+    n_cams: int,
+    n_pts: int,
+    with_depth: bool = True,
+    seed: int = 0,
+    outlier_frac: float = 0.05,
+    perturb: bool = True,
+    max_track: int = 30,
+) -> tuple[BAProblem, dict]:
+    """Returns (problem at the perturbed initial state, ground truth dict)."""
+    rng = np.random.default_rng(seed)
+    R, t, az = _orbit_cameras(rng, n_cams)
+    X = rng.uniform([-3.0, -3.0, -2.0], [3.0, 3.0, 2.0], (n_pts, 3))
+
+    kmax = min(max_track, n_cams)
+    k = np.clip(2 + rng.poisson(3.0, n_pts), 2, kmax).astype(np.int64)
+    # candidate window: cameras nearest in azimuth to the point's own azimuth
+    paz = np.mod(np.arctan2(X[:, 1], X[:, 0]) + rng.normal(0, 0.2, n_pts), 2 * np.pi)
+    wmax = int(min(n_cams, 2 * kmax + 8))
+    obs_cam_l, obs_pt_l, obs_xy_l, obs_z_l = [], [], [], []
+    chunk = 50_000
+    for s in range(0, n_pts, chunk):
+        e = min(n_pts, s + chunk)
+        m = e - s
+        # nearest camera in sorted azimuth, then a symmetric window around it
+        j0 = np.searchsorted(az, paz[s:e]) % n_cams
+        offs = np.zeros(wmax, dtype=np.int64)
+        offs[1::2] = np.arange(1, wmax // 2 + 1)[: len(offs[1::2])]
+        offs[2::2] = -np.arange(1, (wmax - 1) // 2 + 1)[: len(offs[2::2])]
+        cand = (j0[:, None] + offs[None, :]) % n_cams  # [m, wmax] ordered by |offset|
+        Xc = np.einsum("mwij,mj->mwi", R[cand], X[s:e]) + t[cand]
+        z = Xc[..., 2]
+        u = FX * Xc[..., 0] / z + CX
+        v = FY * Xc[..., 1] / z + CY
+        vis = (z > 0.5) & (u >= 0) & (u < WIDTH) & (v >= 0) & (v < HEIGHT)
+        rank = np.cumsum(vis, axis=1)
+        take = vis & (rank <= k[s:e, None])
+        # points seen by fewer than two cameras: fall back to the two nearest regardless
+        few = take.sum(axis=1) < 2
+        if few.any():
+            take[few] = False
+            take[few, :2] = True
+        pi, wi = np.nonzero(take)
+        obs_cam_l.append(cand[pi, wi].astype(np.int32))
+        obs_pt_l.append((pi + s).astype(np.int32))
+        obs_xy_l.append(np.stack([u[pi, wi], v[pi, wi]], axis=1))
+        obs_z_l.append(z[pi, wi])
+        del Xc, z, u, v, vis, rank, take
+    obs_cam = np.concatenate(obs_cam_l)
+    obs_pt = np.concatenate(obs_pt_l)
+    xy_true = np.concatenate(obs_xy_l)
+    z_true = np.concatenate(obs_z_l)
+    n_obs = obs_cam.shape[0]
+
+    xy = xy_true + rng.normal(0.0, 1.0, (n_obs, 2))
+    out = rng.uniform(size=n_obs) < outlier_frac
+    xy[out] += rng.uniform(-20.0, 20.0, (int(out.sum()), 2))
+    xy = xy.astype(np.float16).astype(np.float64)
+
+    kw = {}
+    if with_depth:
+        sigma_l = 0.0263
+        d = z_true * np.exp(rng.normal(0.0, sigma_l, n_obs))
+        gross = rng.uniform(size=n_obs) < 0.03
+        d[gross] *= 1.5
+        valid = rng.uniform(size=n_obs) >= 0.10
+        var = np.maximum((sigma_l * d) ** 2, 0.02**2)
+        kw = dict(
+            dobs_cam=obs_cam[valid],
+            dobs_pt=obs_pt[valid],
+            dobs_depth=d[valid],
+            dobs_magnitude=(d**2 / np.clip(var, 1e-6, None))[valid],
+            dobs_param=(2.0 * np.sqrt(var) / d)[valid],
+            depth_loss_type=LOSS_CAUCHY,
+        )
+
+    q_true = quat_from_R(R)
+    q0, t0, X0 = q_true.copy(), t.copy(), X.copy()
+    if perturb:
+        axis = rng.normal(size=(n_cams, 3))
+        axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+        ang = np.deg2rad(0.5)
+        dq = np.concatenate([axis * np.sin(ang / 2), np.full((n_cams, 1), np.cos(ang / 2))], axis=1)
+        dq[0] = [0, 0, 0, 1]
+        q0 = quat_mul(dq, q_true)
+        dt = rng.normal(0.0, 0.05, (n_cams, 3))
+        dt[0] = 0
+        t0 = t + dt
+        X0 = X + rng.normal(0.0, 0.05, (n_pts, 3))
+
+    pose_const = np.zeros(n_cams, np.uint8)
+    pose_const[0] = 1
+    prob = BAProblem(
+        cam_quat=q0,
+        cam_t=t0,
+        pts=X0,
+        cam_intr=np.array([[FX, FY, CX, CY]]),
+        cam_intr_idx=np.zeros(n_cams, np.int32),
+        pose_const=pose_const,
+        pt_const=np.zeros(n_pts, np.uint8),
+        obs_cam=obs_cam,
+        obs_pt=obs_pt,
+        obs_xy=xy,
+        gauge_axis_cam=1 if n_cams > 1 else -1,
+        reproj_loss_type=LOSS_SOFT_L1,
+        reproj_loss_scale=1.5,
+        reproj_loss_magnitude=1.0,
+        **kw,
+    )
+    truth = {"cam_quat": q_true, "cam_t": t, "pts": X}
+    return prob, truth
+
+
+def make_config(name: str, seed: int = 0) -> tuple[BAProblem, dict]:
+    n_cams, n_pts, with_depth = CONFIGS[name]
+    return make_scene(n_cams, n_pts, with_depth=with_depth, seed=seed)
