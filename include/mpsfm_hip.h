@@ -191,6 +191,8 @@ int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms);
  * and rhs (n); n = summary.reduced_dim.  Test/diagnostic entry point. */
 int mpsfm_ba_get_reduced_system(mpsfm_ba_handle* h, double* S, double* rhs, int32_t n);
 int mpsfm_ba_reduced_dim(mpsfm_ba_handle* h);
+/* Solution y (scaled coordinates, length n) of the last dense solve.  Test/diagnostic. */
+int mpsfm_ba_get_dense_solution(mpsfm_ba_handle* h, double* y, int32_t n);
 /* Factor + solve only, on the last assembled system (prices the MFMA dense solve). */
 int mpsfm_ba_dense_solve_once(mpsfm_ba_handle* h, float* elapsed_ms);
 

@@ -1,0 +1,731 @@
+// Track-sweep kernels of the bundle-adjustment hot path (gfx950).
+//
+// Replaces what Ceres does per LM iteration inside pyceres.solve for the problem assembled by
+// reference mpsfm/sfm/mapper/bundle_adjustment.py:67-185:
+//   k_track_sweep   residual + analytic Jacobian evaluation of every (camera, landmark) record,
+//                   J^T J block accumulation and the landmark Schur reduce.  One workgroup owns a
+//                   chunk of consecutive landmarks; W blocks never leave LDS; the chunk's
+//                   contributions to the reduced camera system are summed in an LDS tile of
+//                   6x6 blocks (ds_add_f64) and flushed once with global_atomic_add_f64.
+//   k_update_sweep  back-substitution of the landmark steps, model cost change, candidate
+//                   landmarks and the candidate cost in one pass over the same chunks.
+#include "common.h"
+
+namespace mpsfm {
+
+struct RecLin {
+  double Jc[18];  // 3 x 6 (rows 0,1 reprojection, row 2 log-depth), robustified + scaled
+  double Jp[9];   // 3 x 3
+  double r[3];
+  double cost;
+  bool ok;
+};
+
+// residual blocks of one merged record at camera `cam` (table row) and landmark X
+__device__ __forceinline__ void linearize_record(const double* __restrict__ cam, const double* X,
+                                                 const double* psc, uint32_t meta, double u, double v,
+                                                 double d, double m, double a, const LossParams& L,
+                                                 RecLin& o) {
+  double c[24];
+  const double2* c2 = reinterpret_cast<const double2*>(cam);
+#pragma unroll
+  for (int i = 0; i < 11; ++i) { const double2 t = c2[i]; c[2 * i] = t.x; c[2 * i + 1] = t.y; }
+  const double* R = c; const double* t = c + 9; const double* K = c + 12; const double* cs = c + 16;
+  const double Y0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+  const double Y1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+  const double Y2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+  const double Xc = Y0 + t[0], Yc = Y1 + t[1], Zc = Y2 + t[2];
+  const double iz = 1.0 / Zc;
+  o.cost = 0.0;
+  o.ok = true;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) o.Jc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.Jp[i] = 0.0;
+  o.r[0] = o.r[1] = o.r[2] = 0.0;
+  if (meta & kRecHasReproj) {
+    const double r0 = K[0] * Xc * iz + K[2] - u;
+    const double r1 = K[1] * Yc * iz + K[3] - v;
+    double rho0, rho1;
+    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
+    o.cost += 0.5 * L.reproj_mag * rho0;
+    o.ok = o.ok && isfinite(r0) && isfinite(r1);
+    const double w = sqrt(L.reproj_mag * rho1);
+    const double a00 = w * K[0] * iz, a02 = -w * K[0] * Xc * iz * iz;
+    const double a11 = w * K[1] * iz, a12 = -w * K[1] * Yc * iz * iz;
+    o.r[0] = w * r0; o.r[1] = w * r1;
+    o.Jc[0] = a02 * (2 * Y1) * cs[0];
+    o.Jc[1] = (a00 * (2 * Y2) - a02 * (2 * Y0)) * cs[1];
+    o.Jc[2] = -a00 * (2 * Y1) * cs[2];
+    o.Jc[3] = a00 * cs[3];
+    o.Jc[5] = a02 * cs[5];
+    o.Jc[6] = (a12 * (2 * Y1) - a11 * (2 * Y2)) * cs[0];
+    o.Jc[7] = -a12 * (2 * Y0) * cs[1];
+    o.Jc[8] = a11 * (2 * Y0) * cs[2];
+    o.Jc[10] = a11 * cs[4];
+    o.Jc[11] = a12 * cs[5];
+    o.Jp[0] = (a00 * R[0] + a02 * R[6]) * psc[0];
+    o.Jp[1] = (a00 * R[1] + a02 * R[7]) * psc[1];
+    o.Jp[2] = (a00 * R[2] + a02 * R[8]) * psc[2];
+    o.Jp[3] = (a11 * R[3] + a12 * R[6]) * psc[0];
+    o.Jp[4] = (a11 * R[4] + a12 * R[7]) * psc[1];
+    o.Jp[5] = (a11 * R[5] + a12 * R[8]) * psc[2];
+  }
+  if (meta & kRecHasDepth) {
+    if (!(Zc > 0.0)) {
+      o.ok = false;
+    } else {
+      const double rd = log(Zc) - log(d);
+      double rho0, rho1;
+      loss_eval(L.depth_type, a, rd * rd, rho0, rho1);
+      o.cost += 0.5 * m * rho0;
+      const double w = sqrt(m * rho1) * iz;
+      o.r[2] = sqrt(m * rho1) * rd;
+      o.Jc[12] = w * (2 * Y1) * cs[0];
+      o.Jc[13] = -w * (2 * Y0) * cs[1];
+      o.Jc[17] = w * cs[5];
+      o.Jp[6] = w * R[6] * psc[0];
+      o.Jp[7] = w * R[7] * psc[1];
+      o.Jp[8] = w * R[8] * psc[2];
+    }
+  }
+}
+
+// cost only (candidate point)
+__device__ __forceinline__ double record_cost(const double* __restrict__ cam, const double* X, uint32_t meta,
+                                              double u, double v, double d, double m, double a,
+                                              const LossParams& L, bool& ok) {
+  const double Xc = cam[0] * X[0] + cam[1] * X[1] + cam[2] * X[2] + cam[9];
+  const double Yc = cam[3] * X[0] + cam[4] * X[1] + cam[5] * X[2] + cam[10];
+  const double Zc = cam[6] * X[0] + cam[7] * X[1] + cam[8] * X[2] + cam[11];
+  double cost = 0.0;
+  if (meta & kRecHasReproj) {
+    const double iz = 1.0 / Zc;
+    const double r0 = cam[12] * Xc * iz + cam[14] - u;
+    const double r1 = cam[13] * Yc * iz + cam[15] - v;
+    double rho0, rho1;
+    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
+    cost += 0.5 * L.reproj_mag * rho0;
+    ok = ok && isfinite(r0) && isfinite(r1);
+  }
+  if (meta & kRecHasDepth) {
+    if (!(Zc > 0.0)) {
+      ok = false;
+    } else {
+      const double rd = log(Zc) - log(d);
+      double rho0, rho1;
+      loss_eval(L.depth_type, a, rd * rd, rho0, rho1);
+      cost += 0.5 * m * rho0;
+    }
+  }
+  return cost;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// decode q in [0, k(k+1)/2) -> (i, j), i <= j < k, row-major upper triangle
+__device__ __forceinline__ void tri_decode(int q, int k, int& i, int& j) {
+  const double b = 2.0 * k + 1.0;
+  int ii = (int)((b - sqrt(b * b - 8.0 * (double)q)) * 0.5);
+  if (ii < 0) ii = 0;
+  if (ii > k - 1) ii = k - 1;
+  // row start(i) = i*k - i(i-1)/2
+  while (ii > 0 && ii * k - (ii * (ii - 1)) / 2 > q) --ii;
+  while ((ii + 1) * k - ((ii + 1) * ii) / 2 <= q) ++ii;
+  i = ii;
+  j = q - (ii * k - (ii * (ii - 1)) / 2) + ii;
+}
+
+__constant__ uint8_t c_tile_li[kTileBlocks];
+__constant__ uint8_t c_tile_lj[kTileBlocks];
+
+enum { MODE_FULL = 0, MODE_DIAG = 1 };
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
+  __shared__ double s_tile[kTileBlocks * 36];
+  __shared__ double s_W[kObsMax * kWStride];
+  __shared__ double s_V[kPtsMax * 6];
+  __shared__ double s_g[kPtsMax * 3];
+  __shared__ double s_gc[kTileCams * 6];
+  __shared__ double s_wv[kTileCams * 6];
+  __shared__ double s_du[kTileCams * 6];
+  __shared__ int32_t s_slot[kLocalCamsMax];
+  __shared__ int32_t s_prs[kPtsMax + 1];   // record start (chunk-relative) per landmark
+  __shared__ int32_t s_ppre[kPtsMax + 1];  // pair prefix per landmark
+  __shared__ double s_red[3 * (kThreads / 64)];
+
+  const int tid = threadIdx.x;
+  const ChunkHdr H = A.chunks[blockIdx.x];
+  const int nrec = H.nrec, npt = H.npt, ncam = H.ncam;
+
+  // ---- P0: clear accumulators, stage chunk tables -----------------------------------------
+  if (MODE == MODE_FULL) {
+    for (int i = tid; i < kTileBlocks * 36; i += kThreads) s_tile[i] = 0.0;
+  }
+  for (int i = tid; i < kPtsMax * 6; i += kThreads) s_V[i] = 0.0;
+  for (int i = tid; i < kPtsMax * 3; i += kThreads) s_g[i] = 0.0;
+  if (tid < kTileCams * 6) { s_gc[tid] = 0.0; s_wv[tid] = 0.0; s_du[tid] = 0.0; }
+  if (tid < ncam) s_slot[tid] = A.chunk_cams[H.cam0 + tid];
+  if (tid <= npt) {
+    s_prs[tid] = A.pt_rec_start[H.pt0 + tid] - H.rec0;
+    s_ppre[tid] = (tid < npt) ? A.pt_pair_start[H.pt0 + tid] : H.npairs;
+  }
+  __syncthreads();
+
+  // ---- P1: per-record residual / Jacobian, J^T J blocks ------------------------------------
+  double my_cost = 0.0;
+  int my_bad = 0;
+  if (tid < nrec) {
+    const int rix = H.rec0 + tid;
+    const uint32_t meta = A.rec_meta[rix];
+    const int cam = A.rec_cam[rix];
+    const int lcam = meta & 0xff;
+    const int lpt = (meta >> 8) & 0xff;
+    const double2 xy = reinterpret_cast<const double2*>(A.rec_xy)[rix];
+    double d = 1.0, m = 0.0, a = 1.0;
+    if (meta & kRecHasDepth) { d = A.rec_d[rix]; m = A.rec_m[rix]; a = A.rec_a[rix]; }
+    const int pix = H.pt0 + lpt;
+    const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
+    const double psc[3] = {A.ps[3 * pix], A.ps[3 * pix + 1], A.ps[3 * pix + 2]};
+    RecLin L;
+    linearize_record(A.camtab + (size_t)cam * kCamRec, X, psc, meta, xy.x, xy.y, d, m, a, A.loss, L);
+    my_cost = L.cost;
+    my_bad = L.ok ? 0 : 1;
+    if (L.ok) {
+      // landmark block
+      if (psc[0] != 0.0) {
+        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double j0 = L.Jp[3 * r], j1 = L.Jp[3 * r + 1], j2 = L.Jp[3 * r + 2];
+          V[0] += j0 * j0; V[1] += j0 * j1; V[2] += j0 * j2; V[3] += j1 * j1; V[4] += j1 * j2; V[5] += j2 * j2;
+          g[0] += j0 * L.r[r]; g[1] += j1 * L.r[r]; g[2] += j2 * L.r[r];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&s_V[lpt * 6 + k], V[k]);
+        if (MODE == MODE_FULL) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) atomicAdd(&s_g[lpt * 3 + k], g[k]);
+        }
+      }
+      if (lcam != (int)kLcamConst) {
+        const int slot = s_slot[lcam];
+        // diag(U)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const double du = L.Jc[i] * L.Jc[i] + L.Jc[6 + i] * L.Jc[6 + i] + L.Jc[12 + i] * L.Jc[12 + i];
+          if (lcam < kTileCams) atomicAdd(&s_du[lcam * 6 + i], du);
+          else atomicAdd(&A.diagU[(size_t)slot * 6 + i], du);
+        }
+        if (MODE == MODE_FULL) {
+          // g_c and the upper triangle of U_c
+          double* dstU = (lcam < kTileCams) ? &s_tile[(lcam * kTileCams - (lcam * (lcam - 1)) / 2) * 36]
+                                            : &A.Sblk[ut_block(slot, slot, A.ncv) * 36];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const double gci = L.Jc[i] * L.r[0] + L.Jc[6 + i] * L.r[1] + L.Jc[12 + i] * L.r[2];
+            if (lcam < kTileCams) atomicAdd(&s_gc[lcam * 6 + i], gci);
+            else atomicAdd(&A.gc[(size_t)slot * 6 + i], gci);
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+              const double uij = L.Jc[i] * L.Jc[j] + L.Jc[6 + i] * L.Jc[6 + j] + L.Jc[12 + i] * L.Jc[12 + j];
+              atomicAdd(&dstU[i * 6 + j], uij);
+            }
+          }
+          // W = Jc^T Jp (6x3) stays in LDS
+          double* w = &s_W[tid * kWStride];
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              w[i * 3 + j] = L.Jc[i] * L.Jp[j] + L.Jc[6 + i] * L.Jp[3 + j] + L.Jc[12 + i] * L.Jp[6 + j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P2: per-landmark (V + D)^-1 ------------------------------------------------------------
+  double my_gmax = 0.0;
+  if (tid < npt) {
+    const int pix = H.pt0 + tid;
+    if (MODE == MODE_DIAG) {
+      A.diagV[3 * pix] = s_V[tid * 6];
+      A.diagV[3 * pix + 1] = s_V[tid * 6 + 3];
+      A.diagV[3 * pix + 2] = s_V[tid * 6 + 5];
+    } else if (A.pt_kv[pix] != 0xffff) {
+      // variable landmark (kv == 0xffff marks a constant one)
+      double V[6], Vi[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) V[k] = s_V[tid * 6 + k];
+      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
+      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
+      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
+      if (!spd3_inverse(V, Vi)) {
+        my_bad = 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Vi[k] = 0.0;
+      }
+      const double g0 = s_g[tid * 3], g1 = s_g[tid * 3 + 1], g2 = s_g[tid * 3 + 2];
+      double vg[3];
+      sym3_mul(Vi, g0, g1, g2, vg);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s_V[tid * 6 + k] = Vi[k];
+      s_g[tid * 3] = vg[0]; s_g[tid * 3 + 1] = vg[1]; s_g[tid * 3 + 2] = vg[2];
+      const double p0 = A.ps[3 * pix], p1 = A.ps[3 * pix + 1], p2 = A.ps[3 * pix + 2];
+      my_gmax = fmax(fabs(g0 / p0), fmax(fabs(g1 / p1), fabs(g2 / p2)));
+    }
+  }
+  if (MODE == MODE_FULL) {
+    __syncthreads();
+
+    // ---- P3a: rhs part  sum_p W Vinv g_p ------------------------------------------------------
+    if (tid < nrec) {
+      const uint32_t meta = A.rec_meta[H.rec0 + tid];
+      const int lcam = meta & 0xff;
+      const int lpt = (meta >> 8) & 0xff;
+      if (lcam != (int)kLcamConst && A.pt_kv[H.pt0 + lpt] != 0xffff) {
+        const double* w = &s_W[tid * kWStride];
+        const double v0 = s_g[lpt * 3], v1 = s_g[lpt * 3 + 1], v2 = s_g[lpt * 3 + 2];
+        const int slot = s_slot[lcam];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const double x = w[i * 3] * v0 + w[i * 3 + 1] * v1 + w[i * 3 + 2] * v2;
+          if (lcam < kTileCams) atomicAdd(&s_wv[lcam * 6 + i], x);
+          else atomicAdd(&A.wv[(size_t)slot * 6 + i], x);
+        }
+      }
+    }
+
+    // ---- P3b: Schur pairs  S[ci,cj] -= W_i Vinv W_j^T ------------------------------------------
+    for (int e = tid; e < H.npairs; e += kThreads) {
+      // landmark owning pair e
+      int lo = 0, hi = npt;  // s_ppre[lo] <= e < s_ppre[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_ppre[mid] <= e) lo = mid; else hi = mid;
+      }
+      const int lpt = lo;
+      const int kv = A.pt_kv[H.pt0 + lpt];
+      int i, j;
+      tri_decode(e - s_ppre[lpt], kv, i, j);
+      const int ri = s_prs[lpt] + i, rj = s_prs[lpt] + j;
+      const int li = A.rec_meta[H.rec0 + ri] & 0xff, lj = A.rec_meta[H.rec0 + rj] & 0xff;
+      double Vi[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Vi[k] = s_V[lpt * 6 + k];
+      double Y[18], Wj[18];
+      {
+        const double* wi = &s_W[ri * kWStride];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) sym3_mul(Vi, wi[a * 3], wi[a * 3 + 1], wi[a * 3 + 2], &Y[a * 3]);
+        const double* wj = &s_W[rj * kWStride];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Wj[k] = wj[k];
+      }
+      const bool in_tile = (lj < kTileCams);
+      double* dst = in_tile ? &s_tile[(li * kTileCams - (li * (li - 1)) / 2 + (lj - li)) * 36]
+                            : &A.Sblk[ut_block(s_slot[li], s_slot[lj], A.ncv) * 36];
+      if (li != lj) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            const double v = Y[a * 3] * Wj[b * 3] + Y[a * 3 + 1] * Wj[b * 3 + 1] + Y[a * 3 + 2] * Wj[b * 3 + 2];
+            atomicAdd(&dst[a * 6 + b], -v);
+          }
+      } else {
+        // diagonal block keeps its upper triangle only; two records of the same camera add B + B^T
+        const double f = (ri == rj) ? 1.0 : 2.0;
+        double Yj[18];
+        if (ri != rj) {
+          const double* wi = &s_W[ri * kWStride];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) sym3_mul(Vi, Wj[a * 3], Wj[a * 3 + 1], Wj[a * 3 + 2], &Yj[a * 3]);
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+              const double v1 = Y[a * 3] * Wj[b * 3] + Y[a * 3 + 1] * Wj[b * 3 + 1] + Y[a * 3 + 2] * Wj[b * 3 + 2];
+              const double v2 = Yj[a * 3] * wi[b * 3] + Yj[a * 3 + 1] * wi[b * 3 + 1] + Yj[a * 3 + 2] * wi[b * 3 + 2];
+              atomicAdd(&dst[a * 6 + b], -(v1 + v2));
+            }
+        } else {
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+              const double v = Y[a * 3] * Wj[b * 3] + Y[a * 3 + 1] * Wj[b * 3 + 1] + Y[a * 3 + 2] * Wj[b * 3 + 2];
+              atomicAdd(&dst[a * 6 + b], -v);
+            }
+        }
+        (void)f;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P4: flush the LDS tile and per-camera vectors, chunk partials --------------------------
+  if (MODE == MODE_FULL) {
+    for (int idx = tid; idx < kTileBlocks * 36; idx += kThreads) {
+      const double v = s_tile[idx];
+      if (v != 0.0) {
+        const int blk = idx / 36, el = idx - blk * 36;
+        const int li = c_tile_li[blk], lj = c_tile_lj[blk];
+        atomicAdd(&A.Sblk[ut_block(s_slot[li], s_slot[lj], A.ncv) * 36 + el], v);
+      }
+    }
+  }
+  if (tid < kTileCams * 6) {
+    const int lc = tid / 6;
+    if (lc < ncam) {
+      const size_t o = (size_t)s_slot[lc] * 6 + (tid - lc * 6);
+      if (s_du[tid] != 0.0) atomicAdd(&A.diagU[o], s_du[tid]);
+      if (MODE == MODE_FULL) {
+        if (s_gc[tid] != 0.0) atomicAdd(&A.gc[o], s_gc[tid]);
+        if (s_wv[tid] != 0.0) atomicAdd(&A.wv[o], s_wv[tid]);
+      }
+    }
+  }
+  if (MODE == MODE_FULL) {
+    const double c = wave_sum(my_cost);
+    const double b = wave_sum((double)my_bad);
+    const double g = wave_max(my_gmax);
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) { s_red[w] = c; s_red[4 + w] = b; s_red[8 + w] = g; }
+    __syncthreads();
+    if (tid == 0) {
+      double* p = A.part + (size_t)blockIdx.x * 4;
+      p[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+      p[1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+      p[2] = fmax(fmax(s_red[8], s_red[9]), fmax(s_red[10], s_red[11]));
+      p[3] = 0.0;
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------
+// Update sweep: y_p = -(V+D)^-1 (g_p + W^T y_c), model cost change, candidate landmarks, candidate
+// cost.  Recomputes the linearisation (cheaper than storing 240 B per record in HBM).
+__global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
+  __shared__ double s_V[kPtsMax * 6];
+  __shared__ double s_g[kPtsMax * 3];   // g_p + W^T y_c, then y_p
+  __shared__ double s_x2[kPtsMax * 3];  // candidate landmark
+  __shared__ int32_t s_slot[kLocalCamsMax];
+  __shared__ double s_red[5 * (kThreads / 64)];
+
+  const int tid = threadIdx.x;
+  const ChunkHdr H = A.chunks[blockIdx.x];
+  const int nrec = H.nrec, npt = H.npt, ncam = H.ncam;
+  for (int i = tid; i < kPtsMax * 6; i += kThreads) s_V[i] = 0.0;
+  for (int i = tid; i < kPtsMax * 3; i += kThreads) s_g[i] = 0.0;
+  if (tid < ncam) s_slot[tid] = A.chunk_cams[H.cam0 + tid];
+  __syncthreads();
+
+  RecLin L;
+  double mrow[3] = {0, 0, 0};
+  uint32_t meta = 0;
+  int cam = 0, lpt = 0;
+  double2 xy = {0, 0};
+  double d = 1.0, m = 0.0, a = 1.0;
+  bool ok = true;
+  if (tid < nrec) {
+    const int rix = H.rec0 + tid;
+    meta = A.rec_meta[rix];
+    cam = A.rec_cam[rix];
+    const int lcam = meta & 0xff;
+    lpt = (meta >> 8) & 0xff;
+    xy = reinterpret_cast<const double2*>(A.rec_xy)[rix];
+    if (meta & kRecHasDepth) { d = A.rec_d[rix]; m = A.rec_m[rix]; a = A.rec_a[rix]; }
+    const int pix = H.pt0 + lpt;
+    const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
+    const double psc[3] = {A.ps[3 * pix], A.ps[3 * pix + 1], A.ps[3 * pix + 2]};
+    linearize_record(A.camtab + (size_t)cam * kCamRec, X, psc, meta, xy.x, xy.y, d, m, a, A.loss, L);
+    ok = L.ok;
+    if (L.ok) {
+      if (lcam != (int)kLcamConst) {
+        const double* y = A.yc + (size_t)s_slot[lcam] * 6;
+        const double y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3], y4 = y[4], y5 = y[5];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          mrow[r] = L.Jc[6 * r] * y0 + L.Jc[6 * r + 1] * y1 + L.Jc[6 * r + 2] * y2 + L.Jc[6 * r + 3] * y3 +
+                    L.Jc[6 * r + 4] * y4 + L.Jc[6 * r + 5] * y5;
+      }
+      if (psc[0] != 0.0) {
+        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double j0 = L.Jp[3 * r], j1 = L.Jp[3 * r + 1], j2 = L.Jp[3 * r + 2];
+          V[0] += j0 * j0; V[1] += j0 * j1; V[2] += j0 * j2; V[3] += j1 * j1; V[4] += j1 * j2; V[5] += j2 * j2;
+          const double rr = L.r[r] + mrow[r];
+          g[0] += j0 * rr; g[1] += j1 * rr; g[2] += j2 * rr;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&s_V[lpt * 6 + k], V[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) atomicAdd(&s_g[lpt * 3 + k], g[k]);
+      }
+    }
+  }
+  __syncthreads();
+
+  double step_sq = 0.0, xn_sq = 0.0;
+  if (tid < npt) {
+    const int pix = H.pt0 + tid;
+    const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
+    double yp[3] = {0, 0, 0}, X2[3] = {X[0], X[1], X[2]};
+    if (A.pt_kv[pix] != 0xffff) {
+      double V[6], Vi[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) V[k] = s_V[tid * 6 + k];
+      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
+      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
+      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
+      if (!spd3_inverse(V, Vi)) {
+        ok = false;
+      } else {
+        sym3_mul(Vi, -s_g[tid * 3], -s_g[tid * 3 + 1], -s_g[tid * 3 + 2], yp);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double dl = A.ps[3 * pix + k] * yp[k];
+          X2[k] = X[k] + dl;
+          step_sq += dl * dl;
+          xn_sq += X2[k] * X2[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s_g[tid * 3 + k] = yp[k];
+      s_x2[tid * 3 + k] = X2[k];
+      A.pts2[3 * pix + k] = X2[k];
+    }
+  }
+  __syncthreads();
+
+  double mcc = 0.0, cand = 0.0;
+  if (tid < nrec && ok) {
+    const double y0 = s_g[lpt * 3], y1 = s_g[lpt * 3 + 1], y2 = s_g[lpt * 3 + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double mm = mrow[r] + L.Jp[3 * r] * y0 + L.Jp[3 * r + 1] * y1 + L.Jp[3 * r + 2] * y2;
+      mcc -= mm * (L.r[r] + 0.5 * mm);
+    }
+    const double X2[3] = {s_x2[lpt * 3], s_x2[lpt * 3 + 1], s_x2[lpt * 3 + 2]};
+    bool ok2 = true;
+    cand = record_cost(A.camtab2 + (size_t)cam * kCamRec, X2, meta, xy.x, xy.y, d, m, a, A.loss, ok2);
+    if (!ok2) { ok = false; cand = 0.0; }
+  }
+  const double r0 = wave_sum(cand), r1 = wave_sum(ok ? 0.0 : 1.0), r2 = wave_sum(mcc), r3 = wave_sum(step_sq),
+               r4 = wave_sum(xn_sq);
+  const int w = tid >> 6;
+  if ((tid & 63) == 0) { s_red[w] = r0; s_red[4 + w] = r1; s_red[8 + w] = r2; s_red[12 + w] = r3; s_red[16 + w] = r4; }
+  __syncthreads();
+  if (tid < 5) {
+    const double* s = &s_red[4 * tid];
+    A.part2[(size_t)blockIdx.x * 8 + tid] = (s[0] + s[1]) + (s[2] + s[3]);
+  }
+}
+
+// cost of a record list at given cameras / landmarks (fixed blocks, eval_cost): per-block partials
+__global__ __launch_bounds__(kThreads) void k_cost_records(CostArgs A) {
+  __shared__ double s_red[3 * (kThreads / 64)];
+  double cr = 0.0, cd = 0.0, bad = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < A.nrec; i += (int64_t)gridDim.x * kThreads) {
+    const uint32_t meta = A.rec_meta[i];
+    const int pt = A.rec_pt[i];
+    const double X[3] = {A.pts[3 * pt], A.pts[3 * pt + 1], A.pts[3 * pt + 2]};
+    const double* cam = A.camtab + (size_t)A.rec_cam[i] * kCamRec;
+    bool ok = true;
+    double d = 1.0, m = 0.0, a = 1.0;
+    if (meta & kRecHasDepth) { d = A.rec_d[i]; m = A.rec_m[i]; a = A.rec_a[i]; }
+    cr += record_cost(cam, X, meta & ~kRecHasDepth, A.rec_xy[2 * i], A.rec_xy[2 * i + 1], d, m, a, A.loss, ok);
+    cd += record_cost(cam, X, meta & ~kRecHasReproj, 0.0, 0.0, d, m, a, A.loss, ok);
+    if (!ok) bad += 1.0;
+  }
+  cr = wave_sum(cr); cd = wave_sum(cd); bad = wave_sum(bad);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_red[w] = cr; s_red[4 + w] = cd; s_red[8 + w] = bad; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const double* s = &s_red[4 * threadIdx.x];
+    A.part[(size_t)blockIdx.x * 4 + threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+  }
+}
+
+// deterministic column sums (or max for columns flagged in max_mask) of a [rows][stride] array
+__global__ __launch_bounds__(kThreads) void k_reduce_cols(const double* part, int64_t rows, int stride, int ncols,
+                                                          uint32_t max_mask, double* out) {
+  __shared__ double s[kThreads];
+  for (int c = 0; c < ncols; ++c) {
+    const bool is_max = (max_mask >> c) & 1u;
+    double v = 0.0;
+    for (int64_t r = threadIdx.x; r < rows; r += kThreads) {
+      const double x = part[r * stride + c];
+      v = is_max ? fmax(v, x) : v + x;
+    }
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) s[threadIdx.x] = is_max ? fmax(s[threadIdx.x], s[threadIdx.x + off]) : s[threadIdx.x] + s[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = s[0];
+    __syncthreads();
+  }
+}
+
+// ---- camera-side kernels ------------------------------------------------------------------------
+// camera table rows from (q, t, intrinsics, cs)
+__global__ void k_build_camtab(int nc, const double* q, const double* t, const double* intr, const int32_t* intr_idx,
+                               const double* cs, double* camtab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc) return;
+  double* o = camtab + (size_t)i * kCamRec;
+  quat_to_R(q + 4 * i, o);
+  o[9] = t[3 * i]; o[10] = t[3 * i + 1]; o[11] = t[3 * i + 2];
+  const double* K = intr + 4 * intr_idx[i];
+  o[12] = K[0]; o[13] = K[1]; o[14] = K[2]; o[15] = K[3];
+  for (int k = 0; k < 6; ++k) o[16 + k] = cs[6 * i + k];
+  o[22] = o[23] = 0.0;
+}
+
+// Jacobi column scales: cs = mask / (1 + sqrt(diagU)), ps = 1 / (1 + sqrt(diagV)) (0 for constants)
+__global__ void k_cam_scales(int nc, const int32_t* cam_slot, const double* cmask, const double* diagU, int jacobi,
+                             double* cs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc * 6) return;
+  const int slot = cam_slot[i / 6];
+  double v = 0.0;
+  if (slot >= 0) v = jacobi ? cmask[i] / (1.0 + sqrt(diagU[(size_t)slot * 6 + (i % 6)])) : cmask[i];
+  cs[i] = v;
+}
+__global__ void k_pt_scales(int64_t n3, const uint16_t* pt_kv, const double* diagV, int jacobi, double* ps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n3) return;
+  double v = 0.0;
+  if (pt_kv[i / 3] != 0xffff) v = jacobi ? 1.0 / (1.0 + sqrt(diagV[i])) : 1.0;
+  ps[i] = v;
+}
+
+// candidate cameras q2,t2 = x [+] cs.*yc; ambient step / norm partials; camera gradient max norm.
+// Single workgroup (cameras are few); writes scal[U_STEP_SQ_CAMS], [U_XN_SQ_CAMS], [U_GMAX_CAMS].
+__global__ __launch_bounds__(kThreads) void k_cam_update(int nc, const int32_t* cam_slot, const double* q,
+                                                         const double* t, const double* cs, const double* yc,
+                                                         const double* gc, double* q2, double* t2, double* scal) {
+  __shared__ double s_red[3 * (kThreads / 64)];
+  double step = 0.0, xn = 0.0, gmax = 0.0;
+  for (int i = threadIdx.x; i < nc; i += kThreads) {
+    const int slot = cam_slot[i];
+    double qq[4] = {q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]};
+    double tt[3] = {t[3 * i], t[3 * i + 1], t[3 * i + 2]};
+    double qn[4] = {qq[0], qq[1], qq[2], qq[3]}, tn[3] = {tt[0], tt[1], tt[2]};
+    if (slot >= 0) {
+      double dl[6], g[6];
+      for (int k = 0; k < 6; ++k) {
+        const double s = cs[6 * i + k];
+        dl[k] = s * yc[(size_t)slot * 6 + k];
+        g[k] = s > 0.0 ? -gc[(size_t)slot * 6 + k] / s : 0.0;
+      }
+      quat_plus(qq, dl, qn);
+      for (int k = 0; k < 3; ++k) tn[k] = tt[k] + dl[3 + k];
+      double qg[4];
+      quat_plus(qq, g, qg);
+      for (int k = 0; k < 4; ++k) {
+        const double d = qn[k] - qq[k];
+        step += d * d; xn += qn[k] * qn[k];
+        gmax = fmax(gmax, fabs(qg[k] - qq[k]));
+      }
+      for (int k = 0; k < 3; ++k) {
+        const double d = tn[k] - tt[k];
+        step += d * d; xn += tn[k] * tn[k];
+        gmax = fmax(gmax, fabs(g[3 + k]));
+      }
+    }
+    for (int k = 0; k < 4; ++k) q2[4 * i + k] = qn[k];
+    for (int k = 0; k < 3; ++k) t2[3 * i + k] = tn[k];
+  }
+  step = wave_sum(step); xn = wave_sum(xn); gmax = wave_max(gmax);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_red[w] = step; s_red[4 + w] = xn; s_red[8 + w] = gmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    scal[U_STEP_SQ_CAMS] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    scal[U_XN_SQ_CAMS] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    scal[U_GMAX_CAMS] = fmax(fmax(s_red[8], s_red[9]), fmax(s_red[10], s_red[11]));
+  }
+}
+
+// squared ambient norm of the variable landmarks (initial x_norm)
+__global__ __launch_bounds__(kThreads) void k_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts,
+                                                         double* part) {
+  __shared__ double s_red[kThreads / 64];
+  double v = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < np; i += (int64_t)gridDim.x * kThreads)
+    if (pt_kv[i] != 0xffff) v += pts[3 * i] * pts[3 * i] + pts[3 * i + 1] * pts[3 * i + 1] + pts[3 * i + 2] * pts[3 * i + 2];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ---- launch wrappers ------------------------------------------------------------------------------
+void init_tile_tables(hipStream_t) {
+  uint8_t li[kTileBlocks], lj[kTileBlocks];
+  int b = 0;
+  for (int i = 0; i < kTileCams; ++i)
+    for (int j = i; j < kTileCams; ++j) { li[b] = (uint8_t)i; lj[b] = (uint8_t)j; ++b; }
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_tile_li), li, sizeof(li));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_tile_lj), lj, sizeof(lj));
+}
+
+void launch_track_sweep(const SweepArgs& a, int nchunks, bool diag_only, hipStream_t s) {
+  if (nchunks <= 0) return;
+  if (diag_only) hipLaunchKernelGGL(k_track_sweep<MODE_DIAG>, dim3(nchunks), dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL(k_track_sweep<MODE_FULL>, dim3(nchunks), dim3(kThreads), 0, s, a);
+}
+void launch_update_sweep(const SweepArgs& a, int nchunks, hipStream_t s) {
+  if (nchunks <= 0) return;
+  hipLaunchKernelGGL(k_update_sweep, dim3(nchunks), dim3(kThreads), 0, s, a);
+}
+void launch_cost_records(const CostArgs& a, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_cost_records, dim3(nblocks), dim3(kThreads), 0, s, a);
+}
+void launch_reduce_cols(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(kThreads), 0, s, part, rows, stride, ncols, max_mask, out);
+}
+void launch_build_camtab(int nc, const double* q, const double* t, const double* intr, const int32_t* intr_idx,
+                         const double* cs, double* camtab, hipStream_t s) {
+  if (nc <= 0) return;
+  hipLaunchKernelGGL(k_build_camtab, dim3((nc + 127) / 128), dim3(128), 0, s, nc, q, t, intr, intr_idx, cs, camtab);
+}
+void launch_cam_scales(int nc, const int32_t* cam_slot, const double* cmask, const double* diagU, int jacobi,
+                       double* cs, hipStream_t s) {
+  if (nc <= 0) return;
+  hipLaunchKernelGGL(k_cam_scales, dim3((nc * 6 + 127) / 128), dim3(128), 0, s, nc, cam_slot, cmask, diagU, jacobi, cs);
+}
+void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, int jacobi, double* ps, hipStream_t s) {
+  if (np <= 0) return;
+  const int64_t n3 = np * 3;
+  hipLaunchKernelGGL(k_pt_scales, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, s, n3, pt_kv, diagV, jacobi, ps);
+}
+void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs,
+                       const double* yc, const double* gc, double* q2, double* t2, double* scal, hipStream_t s) {
+  hipLaunchKernelGGL(k_cam_update, dim3(1), dim3(kThreads), 0, s, nc, cam_slot, q, t, cs, yc, gc, q2, t2, scal);
+}
+void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_pts_sqnorm, dim3(nblocks), dim3(kThreads), 0, s, np, pt_kv, pts, part);
+}
+
+}  // namespace mpsfm

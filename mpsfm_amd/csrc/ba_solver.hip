@@ -1,0 +1,864 @@
+// Host side of libmpsfm_hip: problem upload, chunking of the landmark tracks, the
+// Levenberg-Marquardt control loop (Ceres 2.1 TrustRegionMinimizer semantics with the default
+// pyceres.SolverOptions() that reference mpsfm/sfm/mapper/bundle_adjustment.py:285-293 uses) and
+// the C ABI of include/mpsfm_hip.h.  All arithmetic on problem data runs in the HIP kernels of
+// ba_kernels.hip / dense_chol.hip; this file only orders launches and takes the accept/reject
+// decisions from a handful of scalars.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace mpsfm {
+
+// ---- declarations of the launch wrappers (ba_kernels.hip, dense_chol.hip) ------------------------
+void init_tile_tables(hipStream_t);
+void launch_track_sweep(const SweepArgs&, int nchunks, bool diag_only, hipStream_t);
+void launch_update_sweep(const SweepArgs&, int nchunks, hipStream_t);
+void launch_cost_records(const CostArgs&, int nblocks, hipStream_t);
+void launch_reduce_cols(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out, hipStream_t);
+void launch_build_camtab(int nc, const double* q, const double* t, const double* intr, const int32_t* intr_idx,
+                         const double* cs, double* camtab, hipStream_t);
+void launch_cam_scales(int nc, const int32_t* cam_slot, const double* cmask, const double* diagU, int jacobi, double* cs, hipStream_t);
+void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, int jacobi, double* ps, hipStream_t);
+void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs, const double* yc,
+                       const double* gc, double* q2, double* t2, double* scal, hipStream_t);
+void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
+void launch_assemble(const AssembleArgs&, hipStream_t);
+void launch_dense_solve(double* A, int nt, int n, double* y, int* fail, hipStream_t);
+
+thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(MPSFM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess) return fail(MPSFM_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return 0;
+}
+template <typename T>
+static int dev_upload(T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace mpsfm
+
+using namespace mpsfm;
+
+struct mpsfm_ba_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  mpsfm_ba_options opt{};
+  LossParams loss{};
+  // sizes
+  int nc = 0, np_user = 0;
+  int64_t np = 0, np_chunked = 0;   // re-ordered landmarks (all referenced) / those inside chunks
+  int64_t nrec = 0, nfixed = 0, nblocks_total = 0, nblocks_reduced = 0;
+  double nblocks_global = 0, nblocks_reduced_global = 0, nvarpts_global = 0;
+  int ncv = 0, n = 0, nt = 0, nchunks = 0;
+  int64_t red_count = 0, sblk_count = 0;
+  std::vector<int32_t> perm;        // re-ordered landmark -> caller's index
+  std::vector<int32_t> cam_slot_h;
+  // device state
+  double *d_q = nullptr, *d_t = nullptr, *d_q2 = nullptr, *d_t2 = nullptr, *d_q0 = nullptr, *d_t0 = nullptr;
+  double *d_pts = nullptr, *d_pts2 = nullptr, *d_pts0 = nullptr;
+  double *d_intr = nullptr, *d_cmask = nullptr, *d_cs = nullptr, *d_camtab = nullptr, *d_camtab2 = nullptr;
+  int32_t *d_intr_idx = nullptr, *d_cam_slot = nullptr;
+  double *d_ps = nullptr, *d_diagV = nullptr;
+  ChunkHdr* d_chunks = nullptr;
+  int32_t *d_chunk_cams = nullptr, *d_rec_cam = nullptr, *d_rec_pt = nullptr, *d_pt_rec_start = nullptr, *d_pt_pair_start = nullptr;
+  uint32_t* d_rec_meta = nullptr;
+  uint16_t* d_pt_kv = nullptr;
+  double *d_rec_xy = nullptr, *d_rec_d = nullptr, *d_rec_m = nullptr, *d_rec_a = nullptr;
+  // fixed blocks (constant camera and constant landmark)
+  int32_t *d_fx_cam = nullptr, *d_fx_pt = nullptr;
+  uint32_t* d_fx_meta = nullptr;
+  double *d_fx_xy = nullptr, *d_fx_d = nullptr, *d_fx_m = nullptr, *d_fx_a = nullptr;
+  // reduced buffer: Sblk | gc | wv | diagU | scalars
+  double* d_red = nullptr;
+  double *d_Sblk = nullptr, *d_gc = nullptr, *d_wv = nullptr, *d_diagU = nullptr, *d_redsc = nullptr;
+  double *d_part = nullptr, *d_part2 = nullptr, *d_scal = nullptr, *d_costpart = nullptr;
+  double* h_scal = nullptr;  // pinned
+  double *d_A = nullptr, *d_yc = nullptr;
+  int* d_fail = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double last_radius = 1e4;
+  bool scales_ready = false;
+};
+
+namespace mpsfm {
+
+static void free_handle(mpsfm_ba_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  void* ptrs[] = {h->d_q, h->d_t, h->d_q2, h->d_t2, h->d_q0, h->d_t0, h->d_pts, h->d_pts2, h->d_pts0, h->d_intr, h->d_cmask,
+                  h->d_cs, h->d_camtab, h->d_camtab2, h->d_intr_idx, h->d_cam_slot, h->d_ps, h->d_diagV, h->d_chunks,
+                  h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_pt_pair_start, h->d_rec_meta, h->d_pt_kv,
+                  h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
+                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_fail};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->h_scal) (void)hipHostFree(h->h_scal);
+  for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static int check_problem(const mpsfm_ba_problem* P) {
+  if (!P) return fail(MPSFM_EINVAL, "problem is NULL");
+  if (P->n_cams < 0 || P->n_pts < 0 || P->n_intr < 0 || P->n_obs < 0 || P->n_dobs < 0) return fail(MPSFM_EINVAL, "negative size");
+  if (P->n_cams > 0 && (!P->cam_intr_idx || !P->pose_const || !P->cam_intr)) return fail(MPSFM_EINVAL, "camera arrays are NULL");
+  if (P->n_pts > 0 && !P->pt_const) return fail(MPSFM_EINVAL, "pt_const is NULL");
+  if (P->n_obs > 0 && (!P->obs_cam || !P->obs_pt || !P->obs_xy)) return fail(MPSFM_EINVAL, "observation arrays are NULL");
+  if (P->n_dobs > 0 && (!P->dobs_cam || !P->dobs_pt || !P->dobs_depth || !P->dobs_magnitude || !P->dobs_param))
+    return fail(MPSFM_EINVAL, "depth observation arrays are NULL");
+  if (P->gauge_axis_cam < -1 || P->gauge_axis_cam >= P->n_cams) return fail(MPSFM_EINVAL, "gauge_axis_cam out of range");
+  for (int i = 0; i < P->n_cams; ++i)
+    if (P->cam_intr_idx[i] < 0 || P->cam_intr_idx[i] >= P->n_intr) return fail(MPSFM_EINVAL, "cam_intr_idx out of range");
+  for (int64_t i = 0; i < P->n_obs; ++i)
+    if (P->obs_cam[i] < 0 || P->obs_cam[i] >= P->n_cams || P->obs_pt[i] < 0 || P->obs_pt[i] >= P->n_pts)
+      return fail(MPSFM_EINVAL, "observation index out of range");
+  for (int64_t i = 0; i < P->n_dobs; ++i) {
+    if (P->dobs_cam[i] < 0 || P->dobs_cam[i] >= P->n_cams || P->dobs_pt[i] < 0 || P->dobs_pt[i] >= P->n_pts)
+      return fail(MPSFM_EINVAL, "depth observation index out of range");
+  }
+  for (int t : {P->reproj_loss_type, P->depth_loss_type})
+    if (t < MPSFM_LOSS_TRIVIAL || t > MPSFM_LOSS_CAUCHY) return fail(MPSFM_EINVAL, "unknown loss type");
+  return 0;
+}
+
+static int allreduce_host(mpsfm_ba_handle* h, double* buf, int64_t count) {
+  if (!h->opt.allreduce) return 0;
+  if (h->opt.allreduce(h->opt.allreduce_user, buf, count, 0, nullptr)) return fail(MPSFM_ECOMM, "all-reduce hook failed (host buffer)");
+  return 0;
+}
+static int allreduce_dev(mpsfm_ba_handle* h, double* buf, int64_t count) {
+  if (!h->opt.allreduce) return 0;
+  if (h->opt.allreduce(h->opt.allreduce_user, buf, count, 1, (void*)h->stream)) return fail(MPSFM_ECOMM, "all-reduce hook failed (device buffer)");
+  return 0;
+}
+
+struct Blk { int32_t cam; int32_t key; uint8_t kind; int64_t src; };
+
+// Build the re-ordered, chunked record tables and upload everything.
+static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_state* st) {
+  const int nc = P->n_cams, npu = P->n_pts;
+  h->nc = nc; h->np_user = npu;
+  h->loss.reproj_type = P->reproj_loss_type; h->loss.reproj_a = P->reproj_loss_scale;
+  h->loss.reproj_mag = P->reproj_loss_magnitude; h->loss.depth_type = P->depth_loss_type;
+
+  // -- cameras of the reduced program: not constant and referenced by a residual block (any shard)
+  std::vector<double> cnt(nc + 1, 0.0);
+  for (int64_t i = 0; i < P->n_obs; ++i) cnt[P->obs_cam[i]] += 1.0;
+  for (int64_t i = 0; i < P->n_dobs; ++i) cnt[P->dobs_cam[i]] += 1.0;
+  if (int rc = allreduce_host(h, cnt.data(), nc)) return rc;
+  h->cam_slot_h.assign(nc, -1);
+  std::vector<double> cmask((size_t)nc * 6, 0.0);
+  h->ncv = 0;
+  for (int i = 0; i < nc; ++i) {
+    if (P->pose_const[i] || cnt[i] == 0.0) continue;
+    h->cam_slot_h[i] = h->ncv++;
+    for (int k = 0; k < 6; ++k) cmask[(size_t)i * 6 + k] = 1.0;
+    if (i == P->gauge_axis_cam) cmask[(size_t)i * 6 + 3] = 0.0;
+  }
+  h->n = 6 * h->ncv;
+  h->nt = (h->n + 31) / 32;
+  const std::vector<int32_t>& slot = h->cam_slot_h;
+
+  // -- residual blocks grouped by landmark
+  std::vector<int64_t> pstart((size_t)npu + 1, 0);
+  for (int64_t i = 0; i < P->n_obs; ++i) pstart[P->obs_pt[i] + 1]++;
+  for (int64_t i = 0; i < P->n_dobs; ++i) pstart[P->dobs_pt[i] + 1]++;
+  for (int p = 0; p < npu; ++p) pstart[p + 1] += pstart[p];
+  std::vector<Blk> blks((size_t)pstart[npu]);
+  {
+    std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
+    for (int64_t i = 0; i < P->n_obs; ++i) {
+      const int c = P->obs_cam[i];
+      blks[fill[P->obs_pt[i]]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 0, i};
+    }
+    for (int64_t i = 0; i < P->n_dobs; ++i) {
+      const int c = P->dobs_cam[i];
+      if (!(P->dobs_depth[i] > 0.0)) return fail(MPSFM_EINVAL, "depth prior must be positive");
+      blks[fill[P->dobs_pt[i]]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 1, i};
+    }
+  }
+  // -- merged records per landmark; fixed blocks aside
+  struct Rec { int32_t cam; int32_t slot; uint32_t flags; double u, v, d, m, a; };
+  std::vector<Rec> recs; recs.reserve(blks.size());
+  std::vector<int64_t> prec((size_t)npu + 1, 0);  // record range per caller landmark
+  std::vector<Rec> fixed;
+  std::vector<int32_t> fixed_pt;
+  auto deff = [&](int cam, int64_t src) {
+    double b = 0.0, s = 0.0;
+    if (P->shift_logscale) { b = P->shift_logscale[2 * cam]; s = P->shift_logscale[2 * cam + 1]; }
+    return P->dobs_depth[src] * std::exp(s) + b;
+  };
+  for (int p = 0; p < npu; ++p) {
+    auto b0 = blks.begin() + pstart[p], b1 = blks.begin() + pstart[p + 1];
+    std::sort(b0, b1, [](const Blk& x, const Blk& y) {
+      if (x.key != y.key) return x.key < y.key;
+      if (x.cam != y.cam) return x.cam < y.cam;
+      if (x.kind != y.kind) return x.kind < y.kind;
+      return x.src < y.src;
+    });
+    prec[p] = (int64_t)recs.size();
+    for (auto it = b0; it != b1;) {
+      auto je = it;
+      while (je != b1 && je->cam == it->cam) ++je;
+      auto mid = it;
+      while (mid != je && mid->kind == 0) ++mid;
+      const int64_t nr = mid - it, nd = je - mid;
+      const bool is_fixed = (slot[it->cam] < 0) && P->pt_const[p];
+      for (int64_t k = 0; k < std::max(nr, nd); ++k) {
+        Rec r{it->cam, slot[it->cam], 0, 0, 0, 1.0, 0.0, 1.0};
+        if (k < nr) { const int64_t s = (it + k)->src; r.flags |= kRecHasReproj; r.u = P->obs_xy[2 * s]; r.v = P->obs_xy[2 * s + 1]; }
+        if (k < nd) {
+          const int64_t s = (mid + k)->src;
+          r.flags |= kRecHasDepth; r.d = deff(it->cam, s); r.m = P->dobs_magnitude[s]; r.a = P->dobs_param[s];
+          if (!(r.d > 0.0)) return fail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive");
+        }
+        if (is_fixed) { fixed.push_back(r); fixed_pt.push_back(p); }
+        else recs.push_back(r);
+      }
+      it = je;
+    }
+  }
+  prec[npu] = (int64_t)recs.size();
+  h->nfixed = (int64_t)fixed.size();
+  h->nblocks_total = P->n_obs + P->n_dobs;
+
+  // -- landmark order: those with records sorted by their camera-slot list, then the rest that
+  //    are referenced by fixed blocks only
+  std::vector<int32_t> order; order.reserve(npu);
+  for (int p = 0; p < npu; ++p) if (prec[p + 1] > prec[p]) order.push_back(p);
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    const int64_t na = prec[a + 1] - prec[a], nb = prec[b + 1] - prec[b];
+    const int64_t m = std::min<int64_t>(std::min(na, nb), 6);
+    for (int64_t k = 0; k < m; ++k) {
+      const int sa = recs[prec[a] + k].slot < 0 ? INT32_MAX : recs[prec[a] + k].slot;
+      const int sb = recs[prec[b] + k].slot < 0 ? INT32_MAX : recs[prec[b] + k].slot;
+      if (sa != sb) return sa < sb;
+    }
+    if (na != nb) return na < nb;
+    return a < b;
+  });
+  h->np_chunked = (int64_t)order.size();
+  {
+    std::vector<uint8_t> seen((size_t)npu + 1, 0);
+    for (int p : order) seen[p] = 1;
+    for (int32_t p : fixed_pt) if (!seen[p]) { seen[p] = 1; order.push_back(p); }
+  }
+  h->np = (int64_t)order.size();
+  h->perm = order;
+  std::vector<int32_t> inv((size_t)npu + 1, -1);
+  for (int64_t k = 0; k < h->np; ++k) inv[order[k]] = (int32_t)k;
+
+  // -- chunking
+  std::vector<ChunkHdr> chunks;
+  std::vector<int32_t> chunk_cams;
+  std::vector<int32_t> rec_cam, rec_pt, pt_rec_start((size_t)h->np + 1, 0), pt_pair_start((size_t)h->np + 1, 0);
+  std::vector<uint32_t> rec_meta;
+  std::vector<uint16_t> pt_kv((size_t)h->np + 1, 0xffff);
+  std::vector<double> rec_xy, rec_d, rec_m, rec_a;
+  rec_cam.reserve(recs.size()); rec_pt.reserve(recs.size()); rec_meta.reserve(recs.size());
+  rec_xy.reserve(2 * recs.size()); rec_d.reserve(recs.size()); rec_m.reserve(recs.size()); rec_a.reserve(recs.size());
+  int64_t nblk_reduced = 0;
+  double nvarpts = 0;
+  {
+    std::vector<int32_t> cur_cams;  // sorted slots of the open chunk
+    int64_t c_first = 0, c_nrec = 0;  // first landmark (re-ordered index), records
+    auto close_chunk = [&](int64_t end_pt) {
+      if (end_pt == c_first) return;
+      ChunkHdr H{};
+      H.rec0 = (int32_t)rec_cam.size(); H.pt0 = (int32_t)c_first; H.npt = (int32_t)(end_pt - c_first);
+      H.cam0 = (int32_t)chunk_cams.size(); H.ncam = (int32_t)cur_cams.size();
+      int pairs = 0;
+      for (int64_t k = c_first; k < end_pt; ++k) {
+        const int p = order[k];
+        pt_rec_start[k] = (int32_t)rec_cam.size();
+        pt_pair_start[k] = pairs;
+        int kv = 0;
+        for (int64_t r = prec[p]; r < prec[p + 1]; ++r) {
+          const Rec& R = recs[r];
+          uint32_t lcam = kLcamConst;
+          if (R.slot >= 0) {
+            lcam = (uint32_t)(std::lower_bound(cur_cams.begin(), cur_cams.end(), R.slot) - cur_cams.begin());
+            ++kv;
+          }
+          rec_cam.push_back(R.cam); rec_pt.push_back((int32_t)k);
+          rec_meta.push_back(lcam | ((uint32_t)(k - c_first) << 8) | R.flags);
+          rec_xy.push_back(R.u); rec_xy.push_back(R.v); rec_d.push_back(R.d); rec_m.push_back(R.m); rec_a.push_back(R.a);
+          nblk_reduced += ((R.flags & kRecHasReproj) ? 1 : 0) + ((R.flags & kRecHasDepth) ? 1 : 0);
+        }
+        if (!P->pt_const[p]) { pt_kv[k] = (uint16_t)kv; pairs += kv * (kv + 1) / 2; nvarpts += 1; }
+      }
+      H.nrec = (int32_t)rec_cam.size() - H.rec0;
+      H.npairs = pairs;
+      chunk_cams.insert(chunk_cams.end(), cur_cams.begin(), cur_cams.end());
+      chunks.push_back(H);
+      cur_cams.clear(); c_first = end_pt; c_nrec = 0;
+    };
+    std::vector<int32_t> pc, uni;
+    for (int64_t k = 0; k < h->np_chunked; ++k) {
+      const int p = order[k];
+      const int64_t r_p = prec[p + 1] - prec[p];
+      pc.clear();
+      for (int64_t r = prec[p]; r < prec[p + 1]; ++r) if (recs[r].slot >= 0) pc.push_back(recs[r].slot);
+      pc.erase(std::unique(pc.begin(), pc.end()), pc.end());  // records are slot-sorted
+      if (r_p > kObsMax || (int)pc.size() > kLocalCamsMax)
+        return fail(MPSFM_EUNSUPPORTED, "a landmark track longer than " + std::to_string(kObsMax) + " records is not supported yet");
+      uni.clear();
+      std::set_union(cur_cams.begin(), cur_cams.end(), pc.begin(), pc.end(), std::back_inserter(uni));
+      const bool too_big = (c_nrec + r_p > kObsMax) || (k - c_first + 1 > kPtsMax) || ((int)uni.size() > kLocalCamsMax);
+      const bool spills = ((int)uni.size() > kTileCams) && (c_nrec >= kObsMax / 2) && ((int)cur_cams.size() <= kTileCams);
+      if (k > c_first && (too_big || spills)) {
+        close_chunk(k);
+        uni = pc;
+      }
+      cur_cams = uni;
+      c_nrec += r_p;
+    }
+    close_chunk(h->np_chunked);
+  }
+  h->nchunks = (int)chunks.size();
+  h->nrec = (int64_t)rec_cam.size();
+  h->nblocks_reduced = nblk_reduced;
+  pt_rec_start[h->np_chunked] = (int32_t)h->nrec;
+  for (int64_t k = h->np_chunked + 1; k <= h->np; ++k) pt_rec_start[k] = (int32_t)h->nrec;
+  {
+    double tot[3] = {(double)h->nblocks_total, (double)nblk_reduced, nvarpts};
+    if (int rc = allreduce_host(h, tot, 3)) return rc;
+    h->nblocks_global = tot[0]; h->nblocks_reduced_global = tot[1]; h->nvarpts_global = tot[2];
+  }
+
+  // -- fixed records (landmark index re-ordered)
+  std::vector<int32_t> fx_cam, fx_pt; std::vector<uint32_t> fx_meta; std::vector<double> fx_xy, fx_d, fx_m, fx_a;
+  for (size_t i = 0; i < fixed.size(); ++i) {
+    fx_cam.push_back(fixed[i].cam); fx_pt.push_back(inv[fixed_pt[i]]); fx_meta.push_back(fixed[i].flags);
+    fx_xy.push_back(fixed[i].u); fx_xy.push_back(fixed[i].v); fx_d.push_back(fixed[i].d); fx_m.push_back(fixed[i].m); fx_a.push_back(fixed[i].a);
+  }
+
+  // -- upload
+  int rc = 0;
+  std::vector<double> intr(P->cam_intr, P->cam_intr + (size_t)P->n_intr * 4);
+  std::vector<int32_t> intr_idx(P->cam_intr_idx, P->cam_intr_idx + nc);
+  if ((rc = dev_upload(&h->d_intr, intr))) return rc;
+  if ((rc = dev_upload(&h->d_intr_idx, intr_idx))) return rc;
+  if ((rc = dev_upload(&h->d_cmask, cmask))) return rc;
+  if ((rc = dev_upload(&h->d_cam_slot, h->cam_slot_h))) return rc;
+  if ((rc = dev_upload(&h->d_chunks, chunks))) return rc;
+  if ((rc = dev_upload(&h->d_chunk_cams, chunk_cams))) return rc;
+  if ((rc = dev_upload(&h->d_rec_cam, rec_cam))) return rc;
+  if ((rc = dev_upload(&h->d_rec_pt, rec_pt))) return rc;
+  if ((rc = dev_upload(&h->d_rec_meta, rec_meta))) return rc;
+  if ((rc = dev_upload(&h->d_rec_xy, rec_xy))) return rc;
+  if ((rc = dev_upload(&h->d_rec_d, rec_d))) return rc;
+  if ((rc = dev_upload(&h->d_rec_m, rec_m))) return rc;
+  if ((rc = dev_upload(&h->d_rec_a, rec_a))) return rc;
+  if ((rc = dev_upload(&h->d_pt_rec_start, pt_rec_start))) return rc;
+  if ((rc = dev_upload(&h->d_pt_pair_start, pt_pair_start))) return rc;
+  if ((rc = dev_upload(&h->d_pt_kv, pt_kv))) return rc;
+  if ((rc = dev_upload(&h->d_fx_cam, fx_cam))) return rc;
+  if ((rc = dev_upload(&h->d_fx_pt, fx_pt))) return rc;
+  if ((rc = dev_upload(&h->d_fx_meta, fx_meta))) return rc;
+  if ((rc = dev_upload(&h->d_fx_xy, fx_xy))) return rc;
+  if ((rc = dev_upload(&h->d_fx_d, fx_d))) return rc;
+  if ((rc = dev_upload(&h->d_fx_m, fx_m))) return rc;
+  if ((rc = dev_upload(&h->d_fx_a, fx_a))) return rc;
+
+  const size_t ncs = (size_t)std::max(nc, 1), nps = (size_t)std::max<int64_t>(h->np, 1);
+  for (double** p : {&h->d_q, &h->d_q2, &h->d_q0}) if ((rc = dev_alloc(p, ncs * 4))) return rc;
+  for (double** p : {&h->d_t, &h->d_t2, &h->d_t0}) if ((rc = dev_alloc(p, ncs * 3))) return rc;
+  for (double** p : {&h->d_pts, &h->d_pts2, &h->d_pts0, &h->d_ps, &h->d_diagV}) if ((rc = dev_alloc(p, nps * 3))) return rc;
+  if ((rc = dev_alloc(&h->d_cs, ncs * 6))) return rc;
+  if ((rc = dev_alloc(&h->d_camtab, ncs * kCamRec))) return rc;
+  if ((rc = dev_alloc(&h->d_camtab2, ncs * kCamRec))) return rc;
+  h->sblk_count = (int64_t)h->ncv * (h->ncv + 1) / 2 * 36;
+  h->red_count = h->sblk_count + 3 * (int64_t)h->n + SC_COUNT;
+  if ((rc = dev_alloc(&h->d_red, (size_t)h->red_count))) return rc;
+  h->d_Sblk = h->d_red; h->d_gc = h->d_red + h->sblk_count; h->d_wv = h->d_gc + h->n; h->d_diagU = h->d_wv + h->n;
+  h->d_redsc = h->d_diagU + h->n;
+  if ((rc = dev_alloc(&h->d_part, (size_t)std::max(h->nchunks, 1) * 4))) return rc;
+  if ((rc = dev_alloc(&h->d_part2, (size_t)std::max(h->nchunks, 1) * 8))) return rc;
+  if ((rc = dev_alloc(&h->d_scal, (size_t)U_COUNT))) return rc;
+  if ((rc = dev_alloc(&h->d_costpart, (size_t)1024 * 4))) return rc;
+  HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * U_COUNT * 2, hipHostMallocDefault));
+  const size_t ntiles = (size_t)(h->nt + 1) * (h->nt + 2) / 2;
+  if ((rc = dev_alloc(&h->d_A, ntiles * 1024))) return rc;
+  if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
+  if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
+  for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipMemset(h->d_ps, 0, nps * 3 * sizeof(double)));
+  HIP_TRY(hipMemset(h->d_yc, 0, (size_t)std::max(h->n, 1) * sizeof(double)));
+  init_tile_tables(h->stream);
+  (void)st;
+  return 0;
+}
+
+static int upload_state(mpsfm_ba_handle* h, const mpsfm_ba_state* st, bool as_initial) {
+  if (!st || (h->nc > 0 && (!st->cam_quat_xyzw || !st->cam_t)) || (h->np > 0 && !st->pts)) return fail(MPSFM_EINVAL, "state is NULL");
+  HIP_TRY(hipMemcpyAsync(h->d_q, st->cam_quat_xyzw, sizeof(double) * 4 * h->nc, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_t, st->cam_t, sizeof(double) * 3 * h->nc, hipMemcpyHostToDevice, h->stream));
+  std::vector<double> sorted((size_t)h->np * 3);
+  for (int64_t k = 0; k < h->np; ++k) {
+    const double* s = st->pts + 3 * (size_t)h->perm[k];
+    sorted[3 * k] = s[0]; sorted[3 * k + 1] = s[1]; sorted[3 * k + 2] = s[2];
+  }
+  if (h->np > 0) HIP_TRY(hipMemcpyAsync(h->d_pts, sorted.data(), sizeof(double) * 3 * h->np, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (as_initial) {
+    HIP_TRY(hipMemcpyAsync(h->d_q0, h->d_q, sizeof(double) * 4 * h->nc, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_t0, h->d_t, sizeof(double) * 3 * h->nc, hipMemcpyDeviceToDevice, h->stream));
+    if (h->np > 0) HIP_TRY(hipMemcpyAsync(h->d_pts0, h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  h->scales_ready = false;
+  return 0;
+}
+
+static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius) {
+  SweepArgs a{};
+  a.chunks = h->d_chunks; a.chunk_cams = h->d_chunk_cams; a.rec_cam = h->d_rec_cam; a.rec_meta = h->d_rec_meta;
+  a.rec_xy = h->d_rec_xy; a.rec_d = h->d_rec_d; a.rec_m = h->d_rec_m; a.rec_a = h->d_rec_a;
+  a.pt_rec_start = h->d_pt_rec_start; a.pt_kv = h->d_pt_kv; a.pt_pair_start = h->d_pt_pair_start;
+  a.camtab = h->d_camtab; a.pts = h->d_pts; a.ps = h->d_ps; a.loss = h->loss;
+  a.radius = radius; a.min_diag = h->opt.min_lm_diagonal; a.max_diag = h->opt.max_lm_diagonal; a.ncv = h->ncv;
+  a.Sblk = h->d_Sblk; a.gc = h->d_gc; a.wv = h->d_wv; a.diagU = h->d_diagU; a.part = h->d_part; a.diagV = h->d_diagV;
+  a.yc = h->d_yc; a.camtab2 = h->d_camtab2; a.pts2 = h->d_pts2; a.part2 = h->d_part2;
+  return a;
+}
+
+// cost of a record list; out[0] reprojection, out[1] depth, out[2] bad count (host values)
+static int cost_of_records(mpsfm_ba_handle* h, int64_t nrec, const int32_t* cam, const int32_t* pt, const uint32_t* meta,
+                           const double* xy, const double* d, const double* m, const double* a, double* out3) {
+  out3[0] = out3[1] = out3[2] = 0.0;
+  if (nrec <= 0) return 0;
+  const int nb = (int)std::min<int64_t>(1024, (nrec + kThreads - 1) / kThreads);
+  CostArgs c{nrec, cam, pt, meta, xy, d, m, a, h->d_camtab, h->d_pts, h->loss, h->d_costpart};
+  launch_cost_records(c, nb, h->stream);
+  launch_reduce_cols(h->d_costpart, nb, 4, 3, 0u, h->d_scal, h->stream);
+  HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  out3[0] = h->h_scal[0]; out3[1] = h->h_scal[1]; out3[2] = h->h_scal[2];
+  return 0;
+}
+
+// Jacobi column scales from the Jacobian at the current state (Ceres: iteration 0 only)
+static int prepare_scales(mpsfm_ba_handle* h) {
+  hipStream_t s = h->stream;
+  launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 0, h->d_cs, s);
+  launch_pt_scales(h->np, h->d_pt_kv, h->d_diagV, 0, h->d_ps, s);
+  launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, s);
+  if (h->opt.jacobi_scaling) {
+    HIP_TRY(hipMemsetAsync(h->d_diagU, 0, sizeof(double) * (size_t)std::max(h->n, 1), s));
+    HIP_TRY(hipMemsetAsync(h->d_diagV, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(h->np, 1), s));
+    SweepArgs a = sweep_args(h, 1.0);
+    launch_track_sweep(a, h->nchunks, true, s);
+    if (int rc = allreduce_dev(h, h->d_diagU, h->n)) return rc;
+    launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 1, h->d_cs, s);
+    launch_pt_scales(h->np, h->d_pt_kv, h->d_diagV, 1, h->d_ps, s);
+    launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, s);
+  }
+  HIP_TRY(hipGetLastError());
+  h->scales_ready = true;
+  return 0;
+}
+
+// one track sweep at the current state: fills the reduced buffer and its scalar tail
+static int run_track_sweep(mpsfm_ba_handle* h, double radius) {
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double) * (size_t)h->red_count, s));
+  SweepArgs a = sweep_args(h, radius);
+  launch_track_sweep(a, h->nchunks, false, s);
+  if (h->nchunks > 0) launch_reduce_cols(h->d_part, h->nchunks, 4, 3, 1u << 2, h->d_redsc, s);
+  h->last_radius = radius;
+  return 0;
+}
+
+static int run_dense(mpsfm_ba_handle* h, double radius) {
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemsetAsync(h->d_fail, 0, sizeof(int), s));
+  if (h->n > 0) {
+    AssembleArgs as{h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
+                    h->opt.max_lm_diagonal, h->d_A};
+    launch_assemble(as, s);
+    launch_dense_solve(h->d_A, h->nt, h->n, h->d_yc, h->d_fail, s);
+  }
+  return 0;
+}
+
+static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
+  using clk = std::chrono::steady_clock;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const mpsfm_ba_options& o = h->opt;
+  std::memset(sum, 0, sizeof(*sum));
+  HIP_TRY(hipStreamSynchronize(s));
+  const auto t_begin = clk::now();
+  sum->num_residual_blocks = (int64_t)h->nblocks_global;
+  sum->reduced_dim = h->n;
+  int64_t n_cost_evals = 0, n_jac_evals = 0;
+
+  // camera table at the initial point (unit scales) for the fixed cost
+  launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 0, h->d_cs, s);
+  launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, s);
+  double fx[3];
+  if (int rc = cost_of_records(h, h->nfixed, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d, h->d_fx_m, h->d_fx_a, fx)) return rc;
+  double fixed = fx[0] + fx[1];
+  if (int rc = allreduce_host(h, &fixed, 1)) return rc;
+  sum->fixed_cost = fixed;
+
+  auto finish = [&](int rc) {
+    sum->num_jacobian_evals = n_jac_evals;
+    sum->num_residual_evals = (int64_t)h->nblocks_reduced_global * (n_cost_evals + n_jac_evals);
+    sum->time_total_s = std::chrono::duration<double>(clk::now() - t_begin).count();
+    return rc;
+  };
+
+  if (h->n == 0 && h->nvarpts_global == 0.0) {
+    double c3[3];
+    if (int rc = cost_of_records(h, h->nrec, h->d_rec_cam, h->d_rec_pt, h->d_rec_meta, h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, c3)) return rc;
+    double c = c3[0] + c3[1];
+    if (int rc = allreduce_host(h, &c, 1)) return rc;
+    sum->initial_cost = sum->final_cost = c + fixed;
+    sum->termination = MPSFM_TERM_NO_VARIABLES;
+    return finish(0);
+  }
+
+  if (int rc = prepare_scales(h)) return rc;
+  if (h->np > 0) HIP_TRY(hipMemcpyAsync(h->d_pts2, h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToDevice, s));
+  // initial x norm: cameras through a zero-step camera update, landmarks by a reduction
+  HIP_TRY(hipMemsetAsync(h->d_yc, 0, sizeof(double) * (size_t)std::max(h->n, 1), s));
+  HIP_TRY(hipMemsetAsync(h->d_scal, 0, sizeof(double) * U_COUNT, s));
+  double x_norm = 0.0;
+  {
+    HIP_TRY(hipMemsetAsync(h->d_gc, 0, sizeof(double) * (size_t)std::max(h->n, 1), s));
+    launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s);
+    const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (h->np + kThreads - 1) / kThreads));
+    launch_pts_sqnorm(h->np, h->d_pt_kv, h->d_pts, h->d_costpart, nb, s);
+    launch_reduce_cols(h->d_costpart, nb, 1, 1, 0u, h->d_scal + U_XN_SQ_PTS, s);
+    HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * U_COUNT, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    double v = h->h_scal[U_XN_SQ_PTS];
+    if (int rc = allreduce_host(h, &v, 1)) return rc;
+    x_norm = std::sqrt(v + h->h_scal[U_XN_SQ_CAMS]);
+  }
+
+  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  double x_cost = 0.0, cur_cost = 0.0;
+  int iter = 0, invalid_run = 0, term = -1;
+  bool check_gradient = true;  // Ceres checks the gradient tolerance at iteration 0 and after each successful step
+  float ms;
+  auto trace = [&](double cost, double rad, int acc) {
+    if (sum->trace_len < MPSFM_MAX_TRACE) {
+      sum->trace_cost[sum->trace_len] = cost; sum->trace_radius[sum->trace_len] = rad;
+      sum->trace_accepted[sum->trace_len] = (uint8_t)acc; sum->trace_len++;
+    }
+  };
+
+  while (term < 0) {
+    if (iter >= o.max_num_iterations) { term = MPSFM_TERM_MAX_ITERATIONS; break; }
+    if (radius <= o.min_trust_region_radius) { term = MPSFM_TERM_MIN_RADIUS; break; }
+    ++iter;
+    // ---- device work of one LM iteration ---------------------------------------------------
+    HIP_TRY(hipEventRecord(h->ev[0], s));
+    if (int rc = run_track_sweep(h, radius)) return rc;
+    if (int rc = allreduce_dev(h, h->d_red, h->red_count)) return rc;
+    HIP_TRY(hipEventRecord(h->ev[1], s));
+    if (int rc = run_dense(h, radius)) return rc;
+    HIP_TRY(hipEventRecord(h->ev[2], s));
+    launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s);
+    launch_build_camtab(h->nc, h->d_q2, h->d_t2, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab2, s);
+    {
+      SweepArgs a = sweep_args(h, radius);
+      launch_update_sweep(a, h->nchunks, s);
+      if (h->nchunks > 0) launch_reduce_cols(h->d_part2, h->nchunks, 8, 5, 0u, h->d_scal, s);
+    }
+    if (int rc = allreduce_dev(h, h->d_scal, 5)) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_scal + U_X_COST, h->d_redsc, sizeof(double) * 3, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipEventRecord(h->ev[3], s));
+    HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * U_COUNT, hipMemcpyDeviceToHost, s));
+    int h_fail = 0;
+    HIP_TRY(hipMemcpyAsync(&h_fail, h->d_fail, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); sum->time_linearize_s += 1e-3 * ms;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); sum->time_dense_s += 1e-3 * ms;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); sum->time_update_s += 1e-3 * ms;
+    ++n_jac_evals; ++n_cost_evals;
+    const double* sc = h->h_scal;
+
+    // ---- decisions (Ceres trust_region_minimizer.cc order) ------------------------------------
+    x_cost = sc[U_X_COST];
+    const bool x_bad = sc[U_X_BAD] > 0.0;  // residual not evaluable or a landmark block not PD
+    if (iter == 1) {
+      if (!std::isfinite(x_cost)) return finish(fail(MPSFM_ENUMERIC, "initial cost is not finite"));
+      sum->initial_cost = x_cost + fixed;
+      cur_cost = x_cost;
+      trace(x_cost + fixed, radius, 1);
+    }
+    if (check_gradient) {
+      check_gradient = false;
+      const double gmax = std::max(sc[U_GMAX_CAMS], sc[U_GMAX_PTS]);
+      if (gmax <= o.gradient_tolerance) { term = MPSFM_TERM_GRADIENT_TOLERANCE; --iter; --n_cost_evals; break; }
+    }
+    const double mcc = sc[U_MCC];
+    const bool solver_ok = !x_bad && h_fail == 0 && std::isfinite(mcc);
+    if (!(solver_ok && mcc > 0.0)) {
+      ++invalid_run;
+      sum->num_unsuccessful_steps++;
+      if (invalid_run >= o.max_num_consecutive_invalid_steps) term = MPSFM_TERM_INVALID_STEPS;
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      trace(cur_cost + fixed, radius, 0);
+      if (o.verbose > 0) std::fprintf(stderr, "[mpsfm_ba] it %3d invalid step (chol_fail=%d mcc=%.3e) radius %.3e\n", iter, h_fail, mcc, radius);
+      continue;
+    }
+    invalid_run = 0;
+    const double cand = (sc[U_BAD] > 0.0 || !std::isfinite(sc[U_CAND_COST])) ? DBL_MAX : sc[U_CAND_COST];
+    const double step_norm = std::sqrt(sc[U_STEP_SQ_PTS] + sc[U_STEP_SQ_CAMS]);
+    if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { term = MPSFM_TERM_PARAMETER_TOLERANCE; break; }
+    const double cost_change = x_cost - cand;
+    if (std::fabs(cost_change) <= o.function_tolerance * x_cost) { term = MPSFM_TERM_FUNCTION_TOLERANCE; break; }
+    const double rel = cost_change / mcc;
+    if (rel > o.min_relative_decrease) {
+      std::swap(h->d_q, h->d_q2); std::swap(h->d_t, h->d_t2); std::swap(h->d_pts, h->d_pts2); std::swap(h->d_camtab, h->d_camtab2);
+      x_norm = std::sqrt(sc[U_XN_SQ_PTS] + sc[U_XN_SQ_CAMS]);
+      cur_cost = cand;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3.0));
+      radius = std::min(o.max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      sum->num_successful_steps++;
+      check_gradient = true;
+      trace(cand + fixed, radius, 1);
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      sum->num_unsuccessful_steps++;
+      trace(cur_cost + fixed, radius, 0);
+    }
+    if (o.verbose > 0)
+      std::fprintf(stderr, "[mpsfm_ba] it %3d cost %.9e cand %.9e rel %.3e radius %.3e |step| %.3e\n", iter, x_cost + fixed,
+                   cand + fixed, rel, radius, step_norm);
+  }
+  sum->final_cost = cur_cost + fixed;
+  sum->num_iterations = iter;
+  sum->termination = term;
+  sum->final_radius = radius;
+  return finish(0);
+}
+
+static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, const mpsfm_ba_options* o, mpsfm_ba_handle** out) {
+  if (!out) return fail(MPSFM_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (int rc = check_problem(P)) return rc;
+  if (!o) return fail(MPSFM_EINVAL, "options is NULL");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MPSFM_ENODEVICE, "no HIP device visible: libmpsfm_hip has no CPU fallback");
+  if (o->device < 0 || o->device >= ndev) return fail(MPSFM_EINVAL, "device ordinal out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, o->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MPSFM_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  HIP_TRY(hipSetDevice(o->device));
+  mpsfm_ba_handle* h = new mpsfm_ba_handle();
+  h->device = o->device; h->opt = *o;
+  if (o->stream) { h->stream = (hipStream_t)o->stream; h->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(MPSFM_EHIP, "hipStreamCreate failed"); }
+    h->own_stream = true;
+  }
+  int rc = build(h, P, st);
+  if (rc == 0 && st) rc = upload_state(h, st, true);
+  if (rc) { free_handle(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+}  // namespace mpsfm
+
+// ---- C ABI ---------------------------------------------------------------------------------------
+extern "C" {
+
+int mpsfm_abi_version(void) { return MPSFM_ABI_VERSION; }
+const char* mpsfm_last_error(void) { return g_err.c_str(); }
+
+int mpsfm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int good = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++good;
+  }
+  return good;
+}
+
+void mpsfm_ba_default_options(mpsfm_ba_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 50;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+}
+
+int mpsfm_ba_create(const mpsfm_ba_problem* problem, const mpsfm_ba_state* initial, const mpsfm_ba_options* options,
+                    mpsfm_ba_handle** out) {
+  return create_impl(problem, initial, options, out);
+}
+
+int mpsfm_ba_set_state(mpsfm_ba_handle* h, const mpsfm_ba_state* state) {
+  if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
+  if (hipSetDevice(h->device) != hipSuccess) return fail(MPSFM_EHIP, "hipSetDevice failed");
+  return upload_state(h, state, false);
+}
+
+int mpsfm_ba_reset_state(mpsfm_ba_handle* h) {
+  if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(h->d_q, h->d_q0, sizeof(double) * 4 * h->nc, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_t, h->d_t0, sizeof(double) * 3 * h->nc, hipMemcpyDeviceToDevice, h->stream));
+  if (h->np > 0) HIP_TRY(hipMemcpyAsync(h->d_pts, h->d_pts0, sizeof(double) * 3 * h->np, hipMemcpyDeviceToDevice, h->stream));
+  h->scales_ready = false;
+  return 0;
+}
+
+int mpsfm_ba_solve_resident(mpsfm_ba_handle* h, mpsfm_ba_summary* summary) {
+  if (!h || !summary) return fail(MPSFM_EINVAL, "handle or summary is NULL");
+  return solve_impl(h, summary);
+}
+
+int mpsfm_ba_get_state(mpsfm_ba_handle* h, mpsfm_ba_state* st) {
+  if (!h || !st) return fail(MPSFM_EINVAL, "handle or state is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(st->cam_quat_xyzw, h->d_q, sizeof(double) * 4 * h->nc, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(st->cam_t, h->d_t, sizeof(double) * 3 * h->nc, hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> sorted((size_t)h->np * 3);
+  if (h->np > 0) HIP_TRY(hipMemcpyAsync(sorted.data(), h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int64_t k = 0; k < h->np; ++k) {
+    double* d = st->pts + 3 * (size_t)h->perm[k];
+    d[0] = sorted[3 * k]; d[1] = sorted[3 * k + 1]; d[2] = sorted[3 * k + 2];
+  }
+  return 0;
+}
+
+void mpsfm_ba_destroy(mpsfm_ba_handle* h) { free_handle(h); }
+
+int mpsfm_ba_solve(const mpsfm_ba_problem* problem, mpsfm_ba_state* state, const mpsfm_ba_options* options,
+                   mpsfm_ba_summary* summary) {
+  if (!state || !summary) return fail(MPSFM_EINVAL, "state or summary is NULL");
+  mpsfm_ba_handle* h = nullptr;
+  int rc = create_impl(problem, state, options, &h);
+  if (rc) return rc;
+  rc = solve_impl(h, summary);
+  if (rc == 0) rc = mpsfm_ba_get_state(h, state);
+  free_handle(h);
+  return rc;
+}
+
+int mpsfm_ba_eval_cost(mpsfm_ba_handle* h, double* cost_reproj, double* cost_depth) {
+  if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 0, h->d_cs, h->stream);
+  launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, h->stream);
+  h->scales_ready = false;
+  double a[3], b[3];
+  if (int rc = cost_of_records(h, h->nrec, h->d_rec_cam, h->d_rec_pt, h->d_rec_meta, h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, a)) return rc;
+  if (int rc = cost_of_records(h, h->nfixed, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d, h->d_fx_m, h->d_fx_a, b)) return rc;
+  if (cost_reproj) *cost_reproj = a[0] + b[0];
+  if (cost_depth) *cost_depth = a[1] + b[1];
+  return 0;
+}
+
+int mpsfm_ba_reduced_dim(mpsfm_ba_handle* h) { return h ? h->n : MPSFM_EINVAL; }
+
+int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms) {
+  if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  if (!h->scales_ready) if (int rc = prepare_scales(h)) return rc;
+  HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double) * (size_t)h->red_count, h->stream));
+  SweepArgs a = sweep_args(h, radius);
+  HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  launch_track_sweep(a, h->nchunks, false, h->stream);
+  HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  if (h->nchunks > 0) launch_reduce_cols(h->d_part, h->nchunks, 4, 3, 1u << 2, h->d_redsc, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+  h->last_radius = radius;
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  if (elapsed_ms) *elapsed_ms = ms;
+  return 0;
+}
+
+int mpsfm_ba_dense_solve_once(mpsfm_ba_handle* h, float* elapsed_ms) {
+  if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  if (int rc = run_dense(h, h->last_radius)) return rc;
+  HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  if (elapsed_ms) *elapsed_ms = ms;
+  return 0;
+}
+
+// S and rhs of the last sweep (with the LM damping of its radius), plus the last dense solution
+int mpsfm_ba_get_reduced_system(mpsfm_ba_handle* h, double* S, double* rhs, int32_t n) {
+  if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
+  if (n != h->n) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
+  HIP_TRY(hipSetDevice(h->device));
+  std::vector<double> red((size_t)h->red_count);
+  HIP_TRY(hipMemcpy(red.data(), h->d_red, sizeof(double) * red.size(), hipMemcpyDeviceToHost));
+  const double* Sb = red.data(); const double* gc = Sb + h->sblk_count; const double* wv = gc + n; const double* dU = wv + n;
+  const mpsfm_ba_options& o = h->opt;
+  for (int R = 0; R < n; ++R)
+    for (int C = 0; C < n; ++C) {
+      const int br = R / 6, a = R % 6, bc = C / 6, b = C % 6;
+      double v;
+      if (br < bc) v = Sb[ut_block(br, bc, h->ncv) * 36 + a * 6 + b];
+      else if (br > bc) v = Sb[ut_block(bc, br, h->ncv) * 36 + b * 6 + a];
+      else v = Sb[ut_block(br, br, h->ncv) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
+      if (R == C) v += std::min(std::max(dU[R], o.min_lm_diagonal), o.max_lm_diagonal) / h->last_radius;
+      if (S) S[(size_t)R * n + C] = v;
+    }
+  if (rhs) for (int i = 0; i < n; ++i) rhs[i] = wv[i] - gc[i];
+  return 0;
+}
+
+int mpsfm_ba_get_dense_solution(mpsfm_ba_handle* h, double* y, int32_t n) {
+  if (!h || !y) return fail(MPSFM_EINVAL, "handle or y is NULL");
+  if (n != h->n) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpy(y, h->d_yc, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

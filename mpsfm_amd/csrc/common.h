@@ -1,0 +1,187 @@
+// Shared device/host definitions for libmpsfm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <math.h>
+
+#include "../../include/mpsfm_hip.h"
+
+namespace mpsfm {
+
+// ---- track-sweep chunk geometry ----------------------------------------------------------
+// A chunk = a group of consecutive (re-ordered) landmarks processed by one workgroup.
+constexpr int kThreads = 256;   // workgroup size of the sweep kernels
+constexpr int kObsMax = 192;    // merged (camera, landmark) records per chunk
+constexpr int kPtsMax = 96;     // landmarks per chunk
+constexpr int kTileCams = 16;   // local cameras whose S blocks are accumulated in LDS
+constexpr int kTileBlocks = kTileCams * (kTileCams + 1) / 2;  // upper block triangle
+constexpr int kLocalCamsMax = 64;  // local camera list length (beyond kTileCams: direct atomics)
+constexpr int kWStride = 19;    // padded row stride (doubles) of the per-record W block in LDS
+constexpr int kCamRec = 24;     // doubles per camera table record
+
+// camera table record: R[9] t[3] K[4] cs[6] pad[2]
+// cs = Jacobi column scale * tangent mask (0 for constant cameras / fixed coordinates)
+
+struct ChunkHdr {
+  int32_t rec0, nrec;    // merged records [rec0, rec0+nrec)
+  int32_t pt0, npt;      // re-ordered landmarks [pt0, pt0+npt)
+  int32_t cam0, ncam;    // local camera list in chunk_cams[cam0 ..)
+  int32_t npairs;        // sum over variable landmarks of kv(kv+1)/2
+  int32_t pad;
+};
+
+// record meta word: lcam | lpt << 8 | flags << 16
+constexpr uint32_t kRecHasReproj = 1u << 16;
+constexpr uint32_t kRecHasDepth = 1u << 17;
+constexpr uint32_t kLcamConst = 255;
+
+struct LossParams {
+  int32_t reproj_type;
+  double reproj_a;
+  double reproj_mag;
+  int32_t depth_type;
+};
+
+// scalar slots of the reduced buffer tail (all-reduced with S)
+enum { SC_COST = 0, SC_BAD = 1, SC_GMAX_PTS = 2, SC_COUNT = 8 };
+
+// scalar slots produced by the update sweep + camera update (host reads these each iteration)
+enum {
+  U_CAND_COST = 0, U_BAD = 1, U_MCC = 2, U_STEP_SQ_PTS = 3, U_XN_SQ_PTS = 4,
+  U_STEP_SQ_CAMS = 5, U_XN_SQ_CAMS = 6, U_GMAX_CAMS = 7, U_X_COST = 8, U_X_BAD = 9,
+  U_GMAX_PTS = 10, U_CHOL_FAIL = 11, U_COUNT = 16
+};
+
+// ---- small device math -------------------------------------------------------------------
+__host__ __device__ inline void loss_eval(int type, double a, double s, double& rho0, double& rho1) {
+  if (type == MPSFM_LOSS_SOFT_L1) {
+    const double b = a * a, c = 1.0 / b;
+    const double sum = 1.0 + s * c;
+    const double tmp = sqrt(sum);
+    rho0 = 2.0 * b * (tmp - 1.0);
+    rho1 = fmax(DBL_MIN, 1.0 / tmp);
+  } else if (type == MPSFM_LOSS_CAUCHY) {
+    const double b = a * a, c = 1.0 / b;
+    const double sum = 1.0 + s * c;
+    rho0 = b * log(sum);
+    rho1 = fmax(DBL_MIN, 1.0 / sum);
+  } else {
+    rho0 = s;
+    rho1 = 1.0;
+  }
+}
+
+__host__ __device__ inline void quat_to_R(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+// EigenQuaternionManifold::Plus, q' = exp(d) * q
+__host__ __device__ inline void quat_plus(const double* q, const double* d, double* out) {
+  const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (n == 0.0) { out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; return; }
+  const double sbd = sin(n) / n;
+  const double px = sbd * d[0], py = sbd * d[1], pz = sbd * d[2], pw = cos(n);
+  const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+  out[0] = pw * qx + px * qw + py * qz - pz * qy;
+  out[1] = pw * qy - px * qz + py * qw + pz * qx;
+  out[2] = pw * qz + px * qy - py * qx + pz * qw;
+  out[3] = pw * qw - px * qx - py * qy - pz * qz;
+}
+
+// 3x3 SPD inverse via LL^T; V packed upper [00 01 02 11 12 22]
+__host__ __device__ inline bool spd3_inverse(const double* V, double* Vi) {
+  const double a = V[0], b = V[1], c = V[2], d = V[3], e = V[4], f = V[5];
+  if (!(a > 0.0)) return false;
+  const double l00 = sqrt(a);
+  const double l10 = b / l00, l20 = c / l00;
+  const double t11 = d - l10 * l10;
+  if (!(t11 > 0.0)) return false;
+  const double l11 = sqrt(t11);
+  const double l21 = (e - l20 * l10) / l11;
+  const double t22 = f - l20 * l20 - l21 * l21;
+  if (!(t22 > 0.0)) return false;
+  const double l22 = sqrt(t22);
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  Vi[0] = i00 * i00 + i10 * i10 + i20 * i20;
+  Vi[1] = i10 * i11 + i20 * i21;
+  Vi[2] = i20 * i22;
+  Vi[3] = i11 * i11 + i21 * i21;
+  Vi[4] = i21 * i22;
+  Vi[5] = i22 * i22;
+  return true;
+}
+
+__host__ __device__ inline void sym3_mul(const double* S, double v0, double v1, double v2, double* o) {
+  o[0] = S[0] * v0 + S[1] * v1 + S[2] * v2;
+  o[1] = S[1] * v0 + S[3] * v1 + S[4] * v2;
+  o[2] = S[2] * v0 + S[4] * v1 + S[5] * v2;
+}
+
+// packed index of the upper block triangle (i <= j) of an ncv x ncv block matrix
+__host__ __device__ inline int64_t ut_block(int64_t i, int64_t j, int64_t ncv) {
+  return i * ncv - (i * (i - 1)) / 2 + (j - i);
+}
+// packed index of lower-triangle tile (ti >= tj)
+__host__ __device__ inline int64_t lt_tile(int64_t ti, int64_t tj) { return ti * (ti + 1) / 2 + tj; }
+
+// ---- kernel argument blocks ---------------------------------------------------------------
+struct SweepArgs {
+  const ChunkHdr* chunks;
+  const int32_t* chunk_cams;     // reduced-system slot of every local camera
+  const int32_t* rec_cam;        // camera index (camera table row)
+  const uint32_t* rec_meta;      // lcam | lpt<<8 | flags<<16
+  const double* rec_xy;          // [nrec][2]
+  const double* rec_d;           // effective prior depth d*exp(s)+b
+  const double* rec_m;           // depth loss magnitude
+  const double* rec_a;           // depth loss scale
+  const int32_t* pt_rec_start;   // [np+1]
+  const uint16_t* pt_kv;         // [np] records with a variable camera (0: constant landmark)
+  const int32_t* pt_pair_start;  // [np] exclusive prefix of kv(kv+1)/2 inside the chunk
+  const double* camtab;          // [nc][24] at the linearisation point
+  const double* pts;             // [np][3]
+  const double* ps;              // [np][3] Jacobi scale (0: constant landmark)
+  LossParams loss;
+  double radius, min_diag, max_diag;
+  int32_t ncv;
+  // outputs of the track sweep (accumulated, caller zeroes)
+  double* Sblk;    // packed upper block triangle, 36 doubles per block
+  double* gc;      // [6 ncv] sum Jc^T r
+  double* wv;      // [6 ncv] sum W Vinv g_p
+  double* diagU;   // [6 ncv] diag(sum Jc^T Jc)
+  double* part;    // [nchunks][4] cost, bad, max|g_p|, -
+  double* diagV;   // DIAG mode: [np][3]
+  // update sweep
+  const double* yc;        // [6 ncv] reduced step (scaled coordinates)
+  const double* camtab2;   // candidate cameras
+  double* pts2;            // candidate landmarks
+  double* part2;           // [nchunks][8]
+};
+
+struct CostArgs {
+  int64_t nrec;
+  const int32_t* rec_cam; const int32_t* rec_pt; const uint32_t* rec_meta; const double* rec_xy;
+  const double* rec_d; const double* rec_m; const double* rec_a;
+  const double* camtab; const double* pts;
+  LossParams loss;
+  double* part;  // [gridDim.x][4]: reproj cost, depth cost, bad
+};
+struct AssembleArgs {
+  const double* Sblk; const double* gc; const double* wv; const double* diagU;
+  int32_t ncv, n, nt;
+  double radius, min_diag, max_diag;
+  double* A;     // tiles
+};
+
+
+}  // namespace mpsfm

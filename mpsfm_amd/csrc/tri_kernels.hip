@@ -1,0 +1,330 @@
+// Per-landmark covariance and per-track triangulation numerics (gfx950).
+//   mpsfm_point_covs          replaces pycolmap.estimate_ba_covariance(POINTS), reference
+//                             mpsfm/sfm/mapper/bundle_adjustment.py:244-261
+//   mpsfm_triangulate_tracks  the arithmetic of COLMAP TriangulateMultiViewPoint reached through
+//                             pycolmap.IncrementalTriangulator (mpsfm/sfm/mapper/triangulator.py:48,123)
+//   mpsfm_filter_tracks       max pairwise triangulation angle / squared reprojection error /
+//                             cheirality used by ObservationManager filters
+//                             (mpsfm/sfm/mapper/base.py:686-797, reconstruction/mixins/points3D_utils.py:64-71,
+//                             mpsfm/utils/geometry.py:54-75)
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace mpsfm {
+
+extern thread_local std::string g_err;
+static int tfail(int code, const std::string& m) { g_err = m; return code; }
+#define TRI_TRY(expr)                                                                                \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) return tfail(MPSFM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct DevBuf {
+  std::vector<void*> ptrs;
+  ~DevBuf() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+  template <typename T>
+  T* up(const T* host, size_t n, bool copy = true) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    if (copy && n && host) (void)hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice);
+    return (T*)p;
+  }
+};
+
+static int check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return tfail(MPSFM_ENODEVICE, "no HIP device visible: libmpsfm_hip has no CPU fallback");
+  if (device < 0 || device >= n) return tfail(MPSFM_EINVAL, "device ordinal out of range");
+  TRI_TRY(hipSetDevice(device));
+  return 0;
+}
+
+// ---- point covariances -------------------------------------------------------------------------
+__global__ void k_pcov_accum(int64_t nobs, const int32_t* cam, const int32_t* pt, const double* q, const double* t,
+                             const double* intr, const int32_t* intr_idx, const double* pts, double mag, double* H) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nobs) return;
+  const int c = cam[i], p = pt[i];
+  double R[9];
+  quat_to_R(q + 4 * c, R);
+  const double* K = intr + 4 * intr_idx[c];
+  const double X0 = pts[3 * p], X1 = pts[3 * p + 1], X2 = pts[3 * p + 2];
+  const double Xc = R[0] * X0 + R[1] * X1 + R[2] * X2 + t[3 * c];
+  const double Yc = R[3] * X0 + R[4] * X1 + R[5] * X2 + t[3 * c + 1];
+  const double Zc = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[3 * c + 2];
+  const double iz = 1.0 / Zc;
+  const double a00 = K[0] * iz, a02 = -K[0] * Xc * iz * iz, a11 = K[1] * iz, a12 = -K[1] * Yc * iz * iz;
+  const double j0[3] = {a00 * R[0] + a02 * R[6], a00 * R[1] + a02 * R[7], a00 * R[2] + a02 * R[8]};
+  const double j1[3] = {a11 * R[3] + a12 * R[6], a11 * R[4] + a12 * R[7], a11 * R[5] + a12 * R[8]};
+  double* h = H + 6 * (size_t)p;
+  atomicAdd(&h[0], mag * (j0[0] * j0[0] + j1[0] * j1[0]));
+  atomicAdd(&h[1], mag * (j0[0] * j0[1] + j1[0] * j1[1]));
+  atomicAdd(&h[2], mag * (j0[0] * j0[2] + j1[0] * j1[2]));
+  atomicAdd(&h[3], mag * (j0[1] * j0[1] + j1[1] * j1[1]));
+  atomicAdd(&h[4], mag * (j0[1] * j0[2] + j1[1] * j1[2]));
+  atomicAdd(&h[5], mag * (j0[2] * j0[2] + j1[2] * j1[2]));
+}
+__global__ void k_pcov_invert(int np, const double* H, double* cov) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  double V[6], Vi[6];
+  for (int k = 0; k < 6; ++k) V[k] = H[6 * (size_t)p + k];
+  double* o = cov + 9 * (size_t)p;
+  if (!spd3_inverse(V, Vi)) {
+    for (int k = 0; k < 9; ++k) o[k] = __builtin_nan("");
+    return;
+  }
+  o[0] = Vi[0]; o[1] = Vi[1]; o[2] = Vi[2];
+  o[3] = Vi[1]; o[4] = Vi[3]; o[5] = Vi[4];
+  o[6] = Vi[2]; o[7] = Vi[4]; o[8] = Vi[5];
+}
+
+// ---- triangulation -------------------------------------------------------------------------------
+// smallest eigenvector of a symmetric 4x4 by cyclic Jacobi rotations
+__device__ inline void sym4_min_eigvec(double A[4][4], double v[4]) {
+  double Q[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+    if (off < 1e-300) break;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q) {
+        const double apq = A[p][q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double qkp = Q[k][p], qkq = Q[k][q];
+          Q[k][p] = c * qkp - s * qkq; Q[k][q] = s * qkp + c * qkq;
+        }
+      }
+  }
+  double best = A[0][0];
+  v[0] = Q[0][0]; v[1] = Q[1][0]; v[2] = Q[2][0]; v[3] = Q[3][0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (A[i][i] < best) { best = A[i][i]; v[0] = Q[0][i]; v[1] = Q[1][i]; v[2] = Q[2][i]; v[3] = Q[3][i]; }
+}
+
+struct TrackArgs {
+  int32_t n_tracks;
+  const double* q; const double* t; const double* intr; const int32_t* intr_idx;
+  const int64_t* start; const int32_t* el_cam; const double* el_xy;
+};
+
+__global__ void k_triangulate(TrackArgs T, double* xyz) {
+  const int tr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tr >= T.n_tracks) return;
+  double A[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int64_t e = T.start[tr]; e < T.start[tr + 1]; ++e) {
+    const int cam = T.el_cam[e];
+    const double* K = T.intr + 4 * T.intr_idx[cam];
+    double R[9];
+    quat_to_R(T.q + 4 * cam, R);
+    double P[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { P[i][0] = R[3 * i]; P[i][1] = R[3 * i + 1]; P[i][2] = R[3 * i + 2]; P[i][3] = T.t[3 * cam + i]; }
+    double x[3] = {(T.el_xy[2 * e] - K[2]) / K[0], (T.el_xy[2 * e + 1] - K[3]) / K[1], 1.0};
+    const double nrm = sqrt(x[0] * x[0] + x[1] * x[1] + 1.0);
+    x[0] /= nrm; x[1] /= nrm; x[2] /= nrm;
+    double xtP[4], term[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xtP[j] = x[0] * P[0][j] + x[1] * P[1][j] + x[2] * P[2][j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) term[i][j] = P[i][j] - x[i] * xtP[j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) A[i][j] += term[0][i] * term[0][j] + term[1][i] * term[1][j] + term[2][i] * term[2][j];
+  }
+  double v[4];
+  sym4_min_eigvec(A, v);
+  xyz[3 * (size_t)tr] = v[0] / v[3]; xyz[3 * (size_t)tr + 1] = v[1] / v[3]; xyz[3 * (size_t)tr + 2] = v[2] / v[3];
+}
+
+__device__ inline void proj_center(const double* R, const double* t, double* C) {
+  C[0] = -(R[0] * t[0] + R[3] * t[1] + R[6] * t[2]);
+  C[1] = -(R[1] * t[0] + R[4] * t[1] + R[7] * t[2]);
+  C[2] = -(R[2] * t[0] + R[5] * t[1] + R[8] * t[2]);
+}
+
+__global__ void k_filter(TrackArgs T, const double* xyz, double* max_angle, double* sq_err, uint8_t* front) {
+  const int tr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tr >= T.n_tracks) return;
+  const double X[3] = {xyz[3 * (size_t)tr], xyz[3 * (size_t)tr + 1], xyz[3 * (size_t)tr + 2]};
+  const int64_t e0 = T.start[tr], e1 = T.start[tr + 1];
+  double best = 0.0;
+  for (int64_t e = e0; e < e1; ++e) {
+    const int cam = T.el_cam[e];
+    const double* K = T.intr + 4 * T.intr_idx[cam];
+    double R[9];
+    quat_to_R(T.q + 4 * cam, R);
+    const double* tt = T.t + 3 * cam;
+    const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + tt[0];
+    const double yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + tt[1];
+    const double zc = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + tt[2];
+    if (front) front[e] = zc >= 2.220446049250313e-16 ? 1 : 0;
+    if (sq_err) {
+      const double du = K[0] * xc / zc + K[2] - T.el_xy[2 * e];
+      const double dv = K[1] * yc / zc + K[3] - T.el_xy[2 * e + 1];
+      sq_err[e] = du * du + dv * dv;
+    }
+    if (max_angle) {
+      double C1[3];
+      proj_center(R, tt, C1);
+      for (int64_t f = e + 1; f < e1; ++f) {
+        const int cam2 = T.el_cam[f];
+        double R2[9], C2[3];
+        quat_to_R(T.q + 4 * cam2, R2);
+        proj_center(R2, T.t + 3 * cam2, C2);
+        double b2 = 0, r1 = 0, r2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          b2 += (C1[k] - C2[k]) * (C1[k] - C2[k]);
+          r1 += (X[k] - C1[k]) * (X[k] - C1[k]);
+          r2 += (X[k] - C2[k]) * (X[k] - C2[k]);
+        }
+        const double den = 2.0 * sqrt(r1 * r2);
+        double ang = 0.0;
+        if (den != 0.0) {
+          double cs = (r1 + r2 - b2) / den;
+          cs = cs > 1.0 ? 1.0 : (cs < -1.0 ? -1.0 : cs);
+          ang = fabs(acos(cs));
+          ang = fmin(ang, M_PI - ang);
+        }
+        best = fmax(best, ang);
+      }
+    }
+  }
+  if (max_angle) max_angle[tr] = best;
+}
+
+static int check_tracks(const mpsfm_tracks* T) {
+  if (!T || T->n_tracks < 0 || T->n_cams < 0) return tfail(MPSFM_EINVAL, "tracks is NULL or has negative sizes");
+  if (T->n_tracks > 0 && !T->track_start) return tfail(MPSFM_EINVAL, "track_start is NULL");
+  if (T->n_tracks == 0) return 0;
+  if (T->track_start[0] != 0) return tfail(MPSFM_EINVAL, "track_start[0] must be 0");
+  for (int i = 0; i < T->n_tracks; ++i)
+    if (T->track_start[i + 1] < T->track_start[i]) return tfail(MPSFM_EINVAL, "track_start must be non-decreasing");
+  const int64_t ne = T->track_start[T->n_tracks];
+  for (int64_t e = 0; e < ne; ++e)
+    if (T->el_cam[e] < 0 || T->el_cam[e] >= T->n_cams) return tfail(MPSFM_EINVAL, "el_cam out of range");
+  for (int i = 0; i < T->n_cams; ++i)
+    if (T->cam_intr_idx[i] < 0 || T->cam_intr_idx[i] >= T->n_intr) return tfail(MPSFM_EINVAL, "cam_intr_idx out of range");
+  return 0;
+}
+
+static int upload_tracks(const mpsfm_tracks* T, DevBuf& B, TrackArgs& a) {
+  const int64_t ne = T->n_tracks > 0 ? T->track_start[T->n_tracks] : 0;
+  a.n_tracks = T->n_tracks;
+  a.q = B.up(T->cam_quat_xyzw, (size_t)T->n_cams * 4);
+  a.t = B.up(T->cam_t, (size_t)T->n_cams * 3);
+  a.intr = B.up(T->cam_intr, (size_t)T->n_intr * 4);
+  a.intr_idx = B.up(T->cam_intr_idx, (size_t)T->n_cams);
+  a.start = B.up(T->track_start, (size_t)T->n_tracks + 1);
+  a.el_cam = B.up(T->el_cam, (size_t)ne);
+  a.el_xy = B.up(T->el_xy, (size_t)ne * 2);
+  if (!a.q || !a.t || !a.intr || !a.intr_idx || !a.start || !a.el_cam || !a.el_xy) return tfail(MPSFM_ENOMEM, "hipMalloc failed");
+  return 0;
+}
+
+}  // namespace mpsfm
+
+using namespace mpsfm;
+
+extern "C" {
+
+int mpsfm_point_covs(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, int32_t device, double* covs) {
+  if (!P || !st || !covs) return tfail(MPSFM_EINVAL, "NULL argument");
+  if (P->n_pts < 0 || P->n_cams < 0 || P->n_obs < 0) return tfail(MPSFM_EINVAL, "negative size");
+  for (int64_t i = 0; i < P->n_obs; ++i)
+    if (P->obs_cam[i] < 0 || P->obs_cam[i] >= P->n_cams || P->obs_pt[i] < 0 || P->obs_pt[i] >= P->n_pts)
+      return tfail(MPSFM_EINVAL, "observation index out of range");
+  for (int i = 0; i < P->n_cams; ++i)
+    if (P->cam_intr_idx[i] < 0 || P->cam_intr_idx[i] >= P->n_intr) return tfail(MPSFM_EINVAL, "cam_intr_idx out of range");
+  if (int rc = check_device(device)) return rc;
+  if (P->n_pts == 0) return 0;
+  DevBuf B;
+  const int32_t* cam = B.up(P->obs_cam, (size_t)P->n_obs);
+  const int32_t* pt = B.up(P->obs_pt, (size_t)P->n_obs);
+  const double* q = B.up(st->cam_quat_xyzw, (size_t)P->n_cams * 4);
+  const double* t = B.up(st->cam_t, (size_t)P->n_cams * 3);
+  const double* intr = B.up(P->cam_intr, (size_t)P->n_intr * 4);
+  const int32_t* iidx = B.up(P->cam_intr_idx, (size_t)P->n_cams);
+  const double* pts = B.up(st->pts, (size_t)P->n_pts * 3);
+  double* H = B.up<double>(nullptr, (size_t)P->n_pts * 6, false);
+  double* dcov = B.up<double>(nullptr, (size_t)P->n_pts * 9, false);
+  if (!cam || !pt || !q || !t || !intr || !iidx || !pts || !H || !dcov) return tfail(MPSFM_ENOMEM, "hipMalloc failed");
+  TRI_TRY(hipMemset(H, 0, sizeof(double) * 6 * (size_t)P->n_pts));
+  if (P->n_obs > 0)
+    hipLaunchKernelGGL(k_pcov_accum, dim3((unsigned)((P->n_obs + 255) / 256)), dim3(256), 0, 0, P->n_obs, cam, pt, q, t, intr,
+                       iidx, pts, P->reproj_loss_magnitude, H);
+  hipLaunchKernelGGL(k_pcov_invert, dim3((P->n_pts + 255) / 256), dim3(256), 0, 0, P->n_pts, H, dcov);
+  TRI_TRY(hipGetLastError());
+  TRI_TRY(hipMemcpy(covs, dcov, sizeof(double) * 9 * (size_t)P->n_pts, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mpsfm_triangulate_tracks(const mpsfm_tracks* T, int32_t device, double* xyz) {
+  if (int rc = check_tracks(T)) return rc;
+  if (!xyz && T->n_tracks > 0) return tfail(MPSFM_EINVAL, "xyz is NULL");
+  if (int rc = check_device(device)) return rc;
+  if (T->n_tracks == 0) return 0;
+  DevBuf B;
+  TrackArgs a{};
+  if (int rc = upload_tracks(T, B, a)) return rc;
+  double* dxyz = B.up<double>(nullptr, (size_t)T->n_tracks * 3, false);
+  if (!dxyz) return tfail(MPSFM_ENOMEM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_triangulate, dim3((T->n_tracks + 127) / 128), dim3(128), 0, 0, a, dxyz);
+  TRI_TRY(hipGetLastError());
+  TRI_TRY(hipMemcpy(xyz, dxyz, sizeof(double) * 3 * (size_t)T->n_tracks, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mpsfm_filter_tracks(const mpsfm_tracks* T, const double* xyz, int32_t device, double* max_tri_angle, double* el_sq_err,
+                        uint8_t* el_front) {
+  if (int rc = check_tracks(T)) return rc;
+  if (!xyz && T->n_tracks > 0) return tfail(MPSFM_EINVAL, "xyz is NULL");
+  if (int rc = check_device(device)) return rc;
+  if (T->n_tracks == 0) return 0;
+  const int64_t ne = T->track_start[T->n_tracks];
+  DevBuf B;
+  TrackArgs a{};
+  if (int rc = upload_tracks(T, B, a)) return rc;
+  const double* dxyz = B.up(xyz, (size_t)T->n_tracks * 3);
+  double* dang = max_tri_angle ? B.up<double>(nullptr, (size_t)T->n_tracks, false) : nullptr;
+  double* derr = el_sq_err ? B.up<double>(nullptr, (size_t)ne, false) : nullptr;
+  uint8_t* dfr = el_front ? B.up<uint8_t>(nullptr, (size_t)ne, false) : nullptr;
+  if (!dxyz || (max_tri_angle && !dang) || (el_sq_err && !derr) || (el_front && !dfr)) return tfail(MPSFM_ENOMEM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_filter, dim3((T->n_tracks + 127) / 128), dim3(128), 0, 0, a, dxyz, dang, derr, dfr);
+  TRI_TRY(hipGetLastError());
+  if (dang) TRI_TRY(hipMemcpy(max_tri_angle, dang, sizeof(double) * (size_t)T->n_tracks, hipMemcpyDeviceToHost));
+  if (derr) TRI_TRY(hipMemcpy(el_sq_err, derr, sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost));
+  if (dfr) TRI_TRY(hipMemcpy(el_front, dfr, (size_t)ne, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

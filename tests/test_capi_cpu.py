@@ -1,0 +1,51 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every declared symbol and refuses to
+compute without a GPU (no silent fallback)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from mpsfm_amd import capi
+from mpsfm_amd.synthetic import make_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mpsfm_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(mpsfm_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    L = capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/mpsfm_hip.h but not exported"
+    assert set(capi.EXPORTS) <= declared
+    assert L.mpsfm_abi_version() == 1
+
+
+def test_default_options_are_ceres_defaults():
+    o = capi.default_options()
+    assert o.max_num_iterations == 50
+    assert o.function_tolerance == 1e-6 and o.gradient_tolerance == 1e-10 and o.parameter_tolerance == 1e-8
+    assert o.initial_trust_region_radius == 1e4 and o.min_relative_decrease == 1e-3
+    assert o.min_lm_diagonal == 1e-6 and o.max_lm_diagonal == 1e32 and o.jacobi_scaling == 1
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    if capi.device_count() > 0:
+        pytest.skip("a gfx950 device is visible")
+    prob, _ = make_scene(3, 30, True, seed=0)
+    with pytest.raises(capi.MpsfmHipError) as e:
+        capi.ba_solve(prob)
+    assert e.value.code == -2
+    with pytest.raises(capi.MpsfmHipError):
+        capi.point_covs(prob)
+
+
+def test_invalid_problem_is_rejected_before_touching_the_device():
+    prob, _ = make_scene(3, 30, True, seed=0)
+    prob.obs_cam[0] = 99  # bypasses BAProblem.validate on purpose
+    with pytest.raises(capi.MpsfmHipError) as e:
+        capi.ba_solve(prob)
+    assert e.value.code == -1
