@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py — prior-regularised global bundle adjustment on MI355X (BASELINE.json metric).
+
+One step = one full BA solve (Ceres-default LM until convergence) of the synthetic 200-image /
+150k-landmark scene with reprojection + log-depth prior blocks (BASELINE config "C3"), starting
+from the same perturbed state every step (device-to-device reset, inside the timed region).
+The problem is resident in HBM before the timed region starts.  With N > 1 ranks the landmarks
+are sharded (each rank owns 150k landmarks around the same 200 cameras: weak scaling) and the
+ranks exchange the reduced camera system with an RCCL all-reduce every LM iteration.
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--kernel-reps", type=int, default=20, help="launches used to time the sweep / dense kernels")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+
+    from mpsfm_amd import capi
+    from mpsfm_amd.synthetic import CONFIGS, algorithmic_bytes_sweep, make_config
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libmpsfm_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    keep = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    prob, _ = make_config(args.config, seed=0, shard=rank)
+    opts = capi.default_options(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    if world > 1:
+        from mpsfm_amd.dist import make_torch_allreduce
+
+        fn, keep = make_torch_allreduce()
+        opts.allreduce = fn
+
+    h = capi.BAHandle(prob, opts)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        h.reset_state()
+        return h.solve()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    sums = [step() for _ in range(args.steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    iters = sum(s["num_iterations"] for s in sums)
+    revals = sum(s["num_residual_evals"] for s in sums)  # already the all-rank total
+    last = sums[-1]
+
+    # ---- roofline of the two priced kernels, timed live with HIP events on the solver's stream
+    h.reset_state()
+    reps = max(1, args.kernel_reps)
+    sweep_ms = float(np.mean([h.sweep_once(1e4) for _ in range(reps + 2)][2:]))
+    dense_ms = float(np.mean([h.dense_solve_once() for _ in range(reps + 2)][2:]))
+    bytes_sweep = algorithmic_bytes_sweep(prob)
+    n = h.reduced_dim
+    flops_dense = n**3 / 3.0 + 2.0 * n * n
+    roof_sweep = {
+        "kernel": "k_track_sweep", "bound": "hbm", "achieved": bytes_sweep / (sweep_ms * 1e-3) / 1e9, "peak": 8000.0,
+        "unit": "GB/s", "traffic": None, "algorithmic_bytes": bytes_sweep, "avg_ms": sweep_ms,
+    }
+    roof_sweep["frac"] = roof_sweep["achieved"] / roof_sweep["peak"]
+    roof_dense = {
+        "kernel": "k_chol_step+k_backsub (reduced camera system)", "bound": "mfma", "achieved": flops_dense / (dense_ms * 1e-3) / 1e12,
+        "peak": 78.6, "unit": "TFLOP/s", "traffic": None, "algorithmic_flops": flops_dense, "avg_ms": dense_ms, "n": n,
+    }
+    roof_dense["frac"] = roof_dense["achieved"] / roof_dense["peak"]
+    t_lin, t_den, t_upd = last["time_linearize_s"], last["time_dense_s"], last["time_update_s"]
+    dominant = roof_dense if t_den > t_lin else roof_sweep
+    other = roof_sweep if dominant is roof_dense else roof_dense
+    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            roof_sweep["traffic"] = tr.get("k_track_sweep_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            pass
+
+    out = {
+        "metric": "BA residual-evals/sec (LM iterations/sec alongside), 200 imgs / 150k pts prior-BA",
+        "value": revals / dt,
+        "unit": "residual-block evals/s",
+        "lm_iterations_per_s": iters / dt,
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.config}: {CONFIGS[args.config][0]} cameras, {CONFIGS[args.config][1]} landmarks per rank, "
+                        f"{prob.n_obs} reprojection + {prob.n_dobs} log-depth blocks per rank, SoftL1/Cauchy, Ceres-default LM",
+            "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
+            "residual_blocks_total": last["num_residual_blocks"],
+        },
+        "solve": {
+            "lm_iterations": last["num_iterations"], "successful": last["num_successful_steps"],
+            "initial_cost": last["initial_cost"], "final_cost": last["final_cost"], "termination": last["termination"],
+            "device_ms": {"track_sweep": 1e3 * t_lin, "dense_solve": 1e3 * t_den, "update_sweep": 1e3 * t_upd,
+                          "total": 1e3 * last["time_total_s"]},
+        },
+        "roofline": dominant,
+        "roofline_other": other,
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, last)
+    if rank == 0:
+        print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, gpu_summary):
+    """The oracle (CPU restatement of the Ceres path, OpenMP over all host cores) on the same
+    single-rank problem: whole solves until the time budget is spent."""
+    from mpsfm_amd.synthetic import make_config
+    from oracle import cpu_oracle as O
+
+    base, _ = make_config(args.config, seed=0, shard=0)
+    t_used, n_solves, iters, revals, final = 0.0, 0, 0, 0, None
+    while n_solves < 1 or (t_used < args.cpu_seconds and n_solves < 8):
+        p = base.copy()
+        t0 = time.perf_counter()
+        s = O.solve(p)
+        t_used += time.perf_counter() - t0
+        n_solves += 1
+        iters += s["num_iterations"]
+        revals += s["num_residual_evals"]
+        final = s["final_cost"]
+    rel = abs(final - gpu_summary["final_cost"]) / final if args.gpus == 1 else None
+    return {
+        "value": revals / t_used, "unit": "residual-block evals/s", "lm_iterations_per_s": iters / t_used,
+        "cores": O.num_threads(), "kind": "port",
+        "sample": f"{n_solves} full solve(s) of the same {args.config} problem ({iters // n_solves} LM iterations each), {t_used:.1f} s",
+        "final_cost": final, "final_cost_rel_diff_vs_gpu": rel, "ms_per_solve": 1e3 * t_used / n_solves,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -107,10 +107,16 @@ def make_scene(
     outlier_frac: float = 0.05,
     perturb: bool = True,
     max_track: int = 30,
+    shard: int = 0,
 ) -> tuple[BAProblem, dict]:
-    """Returns (problem at the perturbed initial state, ground truth dict)."""
-    rng = np.random.default_rng(seed)
-    R, t, az = _orbit_cameras(rng, n_cams)
+    """Returns (problem at the perturbed initial state, ground truth dict).
+
+    Cameras (and their perturbation) depend on `seed` only; landmarks, observations and priors
+    on (`seed`, `shard`), so ranks of a landmark-sharded run draw different landmarks around the
+    same cameras."""
+    rng_cam = np.random.default_rng([seed, 0])
+    rng = np.random.default_rng([seed, 1, shard])
+    R, t, az = _orbit_cameras(rng_cam, n_cams)
     X = rng.uniform([-3.0, -3.0, -2.0], [3.0, 3.0, 2.0], (n_pts, 3))
 
     kmax = min(max_track, n_cams)
@@ -178,13 +184,13 @@ def make_scene(
     q_true = quat_from_R(R)
     q0, t0, X0 = q_true.copy(), t.copy(), X.copy()
     if perturb:
-        axis = rng.normal(size=(n_cams, 3))
+        axis = rng_cam.normal(size=(n_cams, 3))
         axis /= np.linalg.norm(axis, axis=1, keepdims=True)
         ang = np.deg2rad(0.5)
         dq = np.concatenate([axis * np.sin(ang / 2), np.full((n_cams, 1), np.cos(ang / 2))], axis=1)
         dq[0] = [0, 0, 0, 1]
         q0 = quat_mul(dq, q_true)
-        dt = rng.normal(0.0, 0.05, (n_cams, 3))
+        dt = rng_cam.normal(0.0, 0.05, (n_cams, 3))
         dt[0] = 0
         t0 = t + dt
         X0 = X + rng.normal(0.0, 0.05, (n_pts, 3))
@@ -212,6 +218,14 @@ def make_scene(
     return prob, truth
 
 
-def make_config(name: str, seed: int = 0) -> tuple[BAProblem, dict]:
+def make_config(name: str, seed: int = 0, shard: int = 0) -> tuple[BAProblem, dict]:
     n_cams, n_pts, with_depth = CONFIGS[name]
-    return make_scene(n_cams, n_pts, with_depth=with_depth, seed=seed)
+    return make_scene(n_cams, n_pts, with_depth=with_depth, seed=seed, shard=shard)
+
+
+def algorithmic_bytes_sweep(prob: BAProblem) -> int:
+    """Compulsory HBM bytes of one track sweep: 24 B per reprojection block
+    (2 indices + xy), 32 B per depth block (2 indices + d, m, a), 24 B per landmark (xyz read),
+    56 B per camera (pose read) and 8 B per entry of the reduced camera system written once."""
+    n = 6 * prob.n_cams
+    return 24 * prob.n_obs + 32 * prob.n_dobs + 24 * prob.n_pts + 56 * prob.n_cams + 8 * n * n
