@@ -171,6 +171,10 @@ def cpu_baseline(args, gpu_summary):
     from mpsfm_amd.synthetic import make_config
     from oracle import cpu_oracle as O
 
+    # size the OpenMP team to the CPUs this box really grants (affinity / cgroup quota), not to
+    # the host's core count: oversubscribed spin locks make the oracle many times slower
+    cores = int(os.environ.get("MPSFM_ORACLE_THREADS", "0")) or min(O.available_cpus(), 32)
+    O.set_num_threads(cores)
     base, _ = make_config(args.config, seed=0, shard=0)
     t_used, n_solves, iters, revals, final = 0.0, 0, 0, 0, None
     while n_solves < 1 or (t_used < args.cpu_seconds and n_solves < 8):
@@ -185,7 +189,7 @@ def cpu_baseline(args, gpu_summary):
     rel = abs(final - gpu_summary["final_cost"]) / final if args.gpus == 1 else None
     return {
         "value": revals / t_used, "unit": "residual-block evals/s", "lm_iterations_per_s": iters / t_used,
-        "cores": O.num_threads(), "kind": "port",
+        "cores": cores, "kind": "port", "host_cpus_visible": os.cpu_count(),
         "sample": f"{n_solves} full solve(s) of the same {args.config} problem ({iters // n_solves} LM iterations each), {t_used:.1f} s",
         "final_cost": final, "final_cost_rel_diff_vs_gpu": rel, "ms_per_solve": 1e3 * t_used / n_solves,
     }

@@ -566,22 +566,27 @@ __global__ __launch_bounds__(kThreads) void k_cost_records(CostArgs A) {
 // deterministic column sums (or max for columns flagged in max_mask) of a [rows][stride] array
 __global__ __launch_bounds__(kThreads) void k_reduce_cols(const double* part, int64_t rows, int stride, int ncols,
                                                           uint32_t max_mask, double* out) {
-  __shared__ double s[kThreads];
-  for (int c = 0; c < ncols; ++c) {
-    const bool is_max = (max_mask >> c) & 1u;
-    double v = 0.0;
-    for (int64_t r = threadIdx.x; r < rows; r += kThreads) {
-      const double x = part[r * stride + c];
-      v = is_max ? fmax(v, x) : v + x;
+  // fixed summation order (thread-strided rows, wave tree, 4 waves): deterministic run to run
+  __shared__ double s[8 * (kThreads / 64)];
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t r = threadIdx.x; r < rows; r += kThreads) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < ncols) {
+        const double x = part[r * stride + c];
+        v[c] = ((max_mask >> c) & 1u) ? fmax(v[c], x) : v[c] + x;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c < ncols) {
+      const double w = ((max_mask >> c) & 1u) ? wave_max(v[c]) : wave_sum(v[c]);
+      if ((threadIdx.x & 63) == 0) s[c * 4 + (threadIdx.x >> 6)] = w;
     }
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) s[threadIdx.x] = is_max ? fmax(s[threadIdx.x], s[threadIdx.x + off]) : s[threadIdx.x] + s[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[c] = s[0];
-    __syncthreads();
+  __syncthreads();
+  if ((int)threadIdx.x < ncols) {
+    const double* p = &s[threadIdx.x * 4];
+    out[threadIdx.x] = ((max_mask >> threadIdx.x) & 1u) ? fmax(fmax(p[0], p[1]), fmax(p[2], p[3])) : (p[0] + p[1]) + (p[2] + p[3]);
   }
 }
 

@@ -30,7 +30,7 @@ void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const d
                        const double* gc, double* q2, double* t2, double* scal, hipStream_t);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
-void launch_dense_solve(double* A, int nt, int n, double* y, int* fail, hipStream_t);
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t);
 
 thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -96,7 +96,7 @@ struct mpsfm_ba_handle {
   double *d_Sblk = nullptr, *d_gc = nullptr, *d_wv = nullptr, *d_diagU = nullptr, *d_redsc = nullptr;
   double *d_part = nullptr, *d_part2 = nullptr, *d_scal = nullptr, *d_costpart = nullptr;
   double* h_scal = nullptr;  // pinned
-  double *d_A = nullptr, *d_yc = nullptr;
+  double *d_A = nullptr, *d_yc = nullptr, *d_dwork = nullptr;
   int* d_fail = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double last_radius = 1e4;
@@ -112,7 +112,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_cs, h->d_camtab, h->d_camtab2, h->d_intr_idx, h->d_cam_slot, h->d_ps, h->d_diagV, h->d_chunks,
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_pt_pair_start, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
-                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_fail};
+                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -402,6 +402,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * U_COUNT * 2, hipHostMallocDefault));
   const size_t ntiles = (size_t)(h->nt + 1) * (h->nt + 2) / 2;
   if ((rc = dev_alloc(&h->d_A, ntiles * 1024))) return rc;
+  if ((rc = dev_alloc(&h->d_dwork, (size_t)std::max(h->nt, 1) * (1024 + 32)))) return rc;
   if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
   if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
   for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
@@ -499,7 +500,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
     AssembleArgs as{h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
                     h->opt.max_lm_diagonal, h->d_A};
     launch_assemble(as, s);
-    launch_dense_solve(h->d_A, h->nt, h->n, h->d_yc, h->d_fail, s);
+    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s);
   }
   return 0;
 }

@@ -95,33 +95,58 @@ __device__ __forceinline__ void tile_store_acc(Ptr T, int ld, int lane, const v4
         T[(16 * mi + (lane >> 4) + 4 * r) * ld + 16 * ni + (lane & 15)] = acc[mi][ni][r];
 }
 
-// In-LDS Cholesky of a 32x32 tile (row stride 33) by one wave; returns false on a non-positive pivot.
-__device__ __forceinline__ bool tile_potrf_lds(double (*T)[kTile + 1], int lane) {
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// 1/sqrt(d): v_rsq_f64 seed + two Newton steps (off the exact-sqrt/divide latency chain)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double hd = 0.5 * d;
+  y = y * __builtin_fma(-hd * y, y, 1.5);
+  y = y * __builtin_fma(-hd * y, y, 1.5);
+  return y;
+}
+
+// Cholesky of a 32x32 tile held one row per lane (lane i and lane i+32 both hold row i).
+// Column j: d = a_jj (readlane), every lane scales its a[j] by 1/sqrt(d), then a[c] -= a[j] * l_cj
+// with l_cj broadcast from lane c.  On return lane i holds row i of L in a[0..i]; inv[j] (uniform)
+// is written to s_inv.
+__device__ __forceinline__ bool potrf_rows(double (&a)[kTile], int lane, double* s_inv) {
   bool ok = true;
-  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
   for (int j = 0; j < kTile; ++j) {
-    const double d = T[j][j];
-    if (!(d > 0.0) || !isfinite(d)) ok = false;
-    const double s = sqrt(d), inv = 1.0 / s;
-    __syncthreads();
-    if (h == 0) {
-      if (i == j) T[j][j] = s;
-      else if (i > j) T[i][j] *= inv;
-    }
-    __syncthreads();
-    const double lij = T[i][j];
-    for (int c = j + 1 + h; c <= i; c += 2) T[i][c] -= lij * T[c][j];
-    __syncthreads();
+    const double d = readlane_f64(a[j], j);
+    ok = ok && (d > 0.0) && isfinite(d);
+    const double inv = rsqrt_nr(d);
+    if (lane == 0) s_inv[j] = inv;
+    a[j] *= inv;
+#pragma unroll
+    for (int c = j + 1; c < kTile; ++c) a[c] -= a[j] * readlane_f64(a[j], c);
   }
   return ok;
 }
 
+// x <- x L^-T for the row held by this lane; L^T is read from LDS as s_Lt[c*32 + k] = L[k][c]
+// (uniform addresses: broadcast reads), 1/L[c][c] from s_inv.
+__device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt, const double* s_inv) {
+#pragma unroll
+  for (int c = 0; c < kTile; ++c) {
+    x[c] *= s_inv[c];
+#pragma unroll
+    for (int k = c + 1; k < kTile; ++k) x[k] -= x[c] * s_Lt[c * kTile + k];
+  }
+}
+
 // One step of the right-looking factorisation.  j = -1: factor tile column 0 only.  Otherwise:
 // every trailing tile (ti >= tk > j) gets  A[ti][tk] -= L[ti][j] L[tk][j]^T  and the tiles of column
-// j+1 are turned into L right away (each of those waves re-derives and factors the diagonal tile).
-__global__ __launch_bounds__(64) void k_chol_step(double* A, int nt, int j, int* fail) {
-  __shared__ double s_D[kTile][kTile + 1];
-  __shared__ double s_X[kTile][kTile + 1];
+// j+1 are turned into L right away: each of those waves re-derives the updated diagonal tile,
+// factors it in registers and solves its own tile against it.  The wave that owns the diagonal
+// tile also stores L^-T of it (LinvT) for the back substitution.
+__global__ __launch_bounds__(64) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail) {
+  __shared__ double s_T[kTile][kTile + 1];
+  __shared__ double s_Lt[kTile * kTile];
+  __shared__ double s_inv[kTile];
   const int lane = threadIdx.x;
   const int tk = j + 1 + blockIdx.y;
   const int ti = j + 1 + blockIdx.x;
@@ -134,99 +159,154 @@ __global__ __launch_bounds__(64) void k_chol_step(double* A, int nt, int j, int*
     tile_store_acc(C, kTile, lane, acc);
     return;
   }
-  // panel column j+1
+  // ---- panel column j+1 -------------------------------------------------------------------
+  const int row = lane & 31;
+  double a[kTile], x[kTile];
   if (ti == tk) {
-    tile_store_acc(&s_D[0][0], kTile + 1, lane, acc);
+    tile_store_acc(&s_T[0][0], kTile + 1, lane, acc);
     __syncthreads();
-    const bool ok = tile_potrf_lds(s_D, lane);
-    if (!ok && lane == 0) atomicExch(fail, 1);
-    for (int e = lane; e < kTileElems; e += 64) {
-      const int r = e >> 5, c = e & 31;
-      C[e] = (c <= r) ? s_D[r][c] : 0.0;
-    }
-    return;
-  }
-  {
+#pragma unroll
+    for (int c = 0; c < kTile; ++c) a[c] = s_T[row][c];
+#pragma unroll
+    for (int c = 0; c < kTile; ++c) x[c] = (c == row) ? 1.0 : 0.0;  // identity: x L^-T = row of L^-T
+  } else {
     v4d dacc[2][2];
-    const double* Dg = A + lt_tile(tk, tk) * kTileElems;
-    tile_load_acc(Dg, lane, dacc);
+    tile_load_acc(A + lt_tile(tk, tk) * kTileElems, lane, dacc);
     if (j >= 0) {
       const double* Lk = A + lt_tile(tk, j) * kTileElems;
       tile_syrk_sub(Lk, Lk, lane, dacc);
     }
-    tile_store_acc(&s_D[0][0], kTile + 1, lane, dacc);
-    tile_store_acc(&s_X[0][0], kTile + 1, lane, acc);
+    tile_store_acc(&s_T[0][0], kTile + 1, lane, dacc);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kTile; ++c) a[c] = s_T[row][c];
+    __syncthreads();
+    tile_store_acc(&s_T[0][0], kTile + 1, lane, acc);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kTile; ++c) x[c] = s_T[row][c];
   }
-  __syncthreads();
-  tile_potrf_lds(s_D, lane);
-  // X <- X L^-T : row i of X solved against the lower-triangular D
+  const bool ok = potrf_rows(a, lane, s_inv);
   if (lane < kTile) {
-    double x[kTile];
 #pragma unroll
-    for (int c = 0; c < kTile; ++c) x[c] = s_X[lane][c];
-#pragma unroll
-    for (int c = 0; c < kTile; ++c) {
-      double s = x[c];
-#pragma unroll
-      for (int k = 0; k < c; ++k) s -= x[k] * s_D[c][k];
-      x[c] = s / s_D[c][c];
-    }
-#pragma unroll
-    for (int c = 0; c < kTile; ++c) s_X[lane][c] = x[c];
+    for (int c = 0; c < kTile; ++c) s_Lt[c * kTile + lane] = a[c];
   }
   __syncthreads();
-  for (int e = lane; e < kTileElems; e += 64) C[e] = s_X[e >> 5][e & 31];
+  trsm_row(x, s_Lt, s_inv);
+  if (ti == tk) {
+    if (!ok && lane == 0) atomicExch(fail, 1);
+    if (lane < kTile) {
+      double2* dst = reinterpret_cast<double2*>(C + lane * kTile);
+      double2* dinv = reinterpret_cast<double2*>(LinvT + (size_t)tk * kTileElems + lane * kTile);
+#pragma unroll
+      for (int c = 0; c < kTile; c += 2) {
+        dst[c >> 1] = make_double2(c <= lane ? a[c] : 0.0, c + 1 <= lane ? a[c + 1] : 0.0);
+        dinv[c >> 1] = make_double2(x[c], x[c + 1]);
+      }
+    }
+  } else if (lane < kTile) {
+    double2* dst = reinterpret_cast<double2*>(C + lane * kTile);
+#pragma unroll
+    for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(x[c], x[c + 1]);
+  }
 }
 
-// y = L^-T z.  z is row 0 of tile row nt.  Single workgroup; column-oriented so that the tile-row
-// reads are contiguous:  for tj = nt-1 .. 0:  solve L[tj][tj]^T y_j = z_j;  z_c -= L[tj][c]^T y_j, c < tj.
-__global__ __launch_bounds__(256) void k_backsub(const double* A, int nt, int n, double* y) {
-  extern __shared__ double s_z[];  // nt*32 doubles + 32
-  double* s_y = s_z + (size_t)nt * kTile;
+// ---- back substitution  y = L^-T z  in groups of kBsG tile rows --------------------------------
+// z starts as row 0 of tile row nt (forward substitution came with the factorisation).  Groups are
+// processed from the bottom; every workgroup of a launch re-solves the group (its tiles are staged
+// in LDS, the diagonal solves are mat-vecs with the stored L^-T tiles), then workgroup w updates the
+// slice z_w of one earlier tile column with the group's y.
+constexpr int kBsG = 4;
+
+__global__ __launch_bounds__(256) void k_z_init(const double* A, int nt, double* zbuf) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < nt * kTile) zbuf[c] = A[lt_tile(nt, c >> 5) * kTileElems + (c & 31)];
+}
+
+__global__ __launch_bounds__(256) void k_backsub_group(const double* A, const double* LinvT, int nt, int n, int t0, int t1,
+                                                      double* zbuf, double* y) {
+  __shared__ double s_tiles[(kBsG + kBsG * (kBsG - 1) / 2) * kTileElems];  // LinvT of the group, then L[tj][c], c<tj in group
+  __shared__ double s_z[kBsG * kTile];
+  __shared__ double s_y[kBsG * kTile];
+  __shared__ double s_part[8 * kTile];
   const int tid = threadIdx.x;
-  for (int c = tid; c < nt * kTile; c += 256) {
-    const int tj = c >> 5;
-    s_z[c] = A[lt_tile(nt, tj) * kTileElems + (c & 31)];
+  const int G = t1 - t0;
+  // stage tiles
+  for (int g = 0; g < G; ++g) {
+    const double2* src = reinterpret_cast<const double2*>(LinvT + (size_t)(t0 + g) * kTileElems);
+    double2* dst = reinterpret_cast<double2*>(s_tiles + g * kTileElems);
+    for (int e = tid; e < kTileElems / 2; e += 256) dst[e] = src[e];
+  }
+  {
+    int slot = kBsG;
+    for (int g = 1; g < G; ++g)
+      for (int c = 0; c < g; ++c, ++slot) {
+        const double2* src = reinterpret_cast<const double2*>(A + lt_tile(t0 + g, t0 + c) * kTileElems);
+        double2* dst = reinterpret_cast<double2*>(s_tiles + slot * kTileElems);
+        for (int e = tid; e < kTileElems / 2; e += 256) dst[e] = src[e];
+      }
+  }
+  if (tid < G * kTile) s_z[tid] = zbuf[t0 * kTile + tid];
+  // prefetch this workgroup's column tiles L[t0+g][w] into registers: thread (part, q) needs rows 4 part .. +3
+  const int w = blockIdx.x;
+  const bool has_col = (w < t0);
+  const int q = tid & 31, part = tid >> 5;
+  double lc[kBsG][4];
+  if (has_col) {
+#pragma unroll
+    for (int g = 0; g < kBsG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        lc[g][r] = (g < G) ? A[lt_tile(t0 + g, w) * kTileElems + (4 * part + r) * kTile + q] : 0.0;
   }
   __syncthreads();
-  for (int tj = nt - 1; tj >= 0; --tj) {
-    const double* D = A + lt_tile(tj, tj) * kTileElems;
-    if (tid < 64) {
-      // lane k keeps column k of the diagonal tile in registers; the chain runs on readlane
-      // broadcasts:  y_i = z_i / D[i][i];  z_k -= D[i][k] y_i  (k < i)
-      const int k = tid & 31;
-      double col[kTile];
-#pragma unroll
-      for (int i = 0; i < kTile; ++i) col[i] = D[i * kTile + k];
-      double dinv = 1.0;
-#pragma unroll
-      for (int i = 0; i < kTile; ++i) dinv = (i == k) ? 1.0 / col[i] : dinv;
-      double zk = s_z[tj * kTile + k], yres = 0.0;
-#pragma unroll
-      for (int i = kTile - 1; i >= 0; --i) {
-        const double t = zk * dinv;
-        const double yi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), i),
-                                           __builtin_amdgcn_readlane(__double2loint(t), i));
-        yres = (k == i) ? yi : yres;
-        zk -= col[i] * yi;
-      }
-      if (tid < 32) s_y[k] = yres;
+  // solve the group bottom-up
+  for (int g = G - 1; g >= 0; --g) {
+    // y_g = LinvT_g z_g : thread (part, q): partial over columns 4 part .. +3 of row q
+    {
+      const double* T = s_tiles + g * kTileElems + q * kTile + 4 * part;
+      const double* z = s_z + g * kTile + 4 * part;
+      s_part[part * kTile + q] = T[0] * z[0] + T[1] * z[1] + T[2] * z[2] + T[3] * z[3];
     }
     __syncthreads();
-    // z_c -= L[tj][c]^T y_j for all c < tj : element (col c*32+q) -= sum_r L[tj][c][r][q] * y_j[r]
-    for (int idx = tid; idx < tj * kTile; idx += 256) {
-      const int c = idx >> 5, q = idx & 31;
-      const double* Lt = A + lt_tile(tj, c) * kTileElems;
+    if (tid < kTile) {
+      double s = 0.0;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) s += s_part[p * kTile + tid];
+      s_y[g * kTile + tid] = s;
+    }
+    __syncthreads();
+    // z_c -= L[g][c]^T y_g for c < g inside the group
+    for (int idx = tid; idx < g * kTile; idx += 256) {
+      const int c = idx >> 5, qq = idx & 31;
+      const int slot = kBsG + g * (g - 1) / 2 + c;
+      const double* Lt = s_tiles + slot * kTileElems;
       double s = 0.0;
 #pragma unroll 8
-      for (int r = 0; r < kTile; ++r) s += Lt[r * kTile + q] * s_y[r];
-      s_z[idx] -= s;
-    }
-    if (tid < 32) {
-      const int g = tj * kTile + tid;
-      if (g < n) y[g] = s_y[tid];
+      for (int r = 0; r < kTile; ++r) s += Lt[r * kTile + qq] * s_y[g * kTile + r];
+      s_z[c * kTile + qq] -= s;
     }
     __syncthreads();
+  }
+  // update the slice of an earlier tile column
+  if (has_col) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < kBsG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += (g < G) ? lc[g][r] * s_y[g * kTile + 4 * part + r] : 0.0;
+    s_part[part * kTile + q] = s;
+  }
+  __syncthreads();
+  if (has_col && tid < kTile) {
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s += s_part[p * kTile + tid];
+    zbuf[w * kTile + tid] -= s;
+  }
+  if (w == 0 && tid < G * kTile) {
+    const int gidx = t0 * kTile + tid;
+    if (gidx < n) y[gidx] = s_y[tid];
   }
 }
 
@@ -236,16 +316,22 @@ void launch_assemble(const AssembleArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_assemble, dim3((unsigned)ntiles), dim3(256), 0, s, a);
 }
 
-// factor + forward substitution (steps -1 .. nt-2) and back substitution
-void launch_dense_solve(double* A, int nt, int n, double* y, int* fail, hipStream_t s) {
+// factor + forward substitution (steps -1 .. nt-2) and back substitution.
+// work: nt*1024 doubles for L^-T of the diagonal tiles followed by nt*32 doubles for z.
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s) {
   if (nt <= 0) return;
+  double* LinvT = work;
+  double* zbuf = work + (size_t)nt * kTileElems;
   for (int j = -1; j <= nt - 2; ++j) {
     const int rows = nt - j;      // ti in [j+1, nt]
     const int cols = (j < 0) ? 1 : nt - 1 - j;  // tk in [j+1, nt-1]; the first step only factors column 0
-    hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(64), 0, s, A, nt, j, fail);
+    hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(64), 0, s, A, LinvT, nt, j, fail);
   }
-  const size_t lds = ((size_t)nt * kTile + kTile) * sizeof(double);
-  hipLaunchKernelGGL(k_backsub, dim3(1), dim3(256), lds, s, A, nt, n, y);
+  hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
+  for (int t1 = nt; t1 > 0; t1 -= kBsG) {
+    const int t0 = t1 - kBsG > 0 ? t1 - kBsG : 0;
+    hipLaunchKernelGGL(k_backsub_group, dim3(t0 > 0 ? t0 : 1), dim3(256), 0, s, A, LinvT, nt, n, t0, t1, zbuf, y);
+  }
 }
 
 }  // namespace mpsfm

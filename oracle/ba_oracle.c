@@ -1132,3 +1132,11 @@ ORACLE_API int oracle_num_threads(void) {
   return 1;
 #endif
 }
+
+ORACLE_API void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

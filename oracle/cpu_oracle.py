@@ -169,3 +169,26 @@ def make_allreduce(fn):
             return -1
 
     return ALLREDUCE_FN(_cb)
+
+
+def available_cpus() -> int:
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def set_num_threads(n: int) -> None:
+    lib().oracle_set_num_threads(int(n))
