@@ -109,32 +109,69 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 }
 
 // Cholesky of a 32x32 tile held one row per lane (lane i and lane i+32 both hold row i).
-// Column j: d = a_jj (readlane), every lane scales its a[j] by 1/sqrt(d), then a[c] -= a[j] * l_cj
-// with l_cj broadcast from lane c.  On return lane i holds row i of L in a[0..i]; inv[j] (uniform)
-// is written to s_inv.
-__device__ __forceinline__ bool potrf_rows(double (&a)[kTile], int lane, double* s_inv) {
+// Right-looking, software-pipelined by one column so that the only cross-lane traffic on the
+// dependent chain is two readlane broadcasts:
+//   chain(j)  d = a_jj (readlane), inv = rsqrt(d), t = a_ij / d, the NEXT pivot column gets its
+//             update right away (a[j+1] -= t * a_{j+1,j}, readlane), column j (unscaled) goes to LDS
+//   bulk(j-1) a[c] -= t_{j-1} * a_{c,j-1} for c >= j+1 with the column broadcast from LDS; its
+//             reads are issued before chain(j) and consumed after it, hiding the LDS round trip.
+// On return lane i holds row i of L in a[0..i]; s_inv[j] = 1 / L[j][j].
+__device__ __forceinline__ bool potrf_rows(double (&a)[kTile], int lane, double* s_inv, double (*s_col)[kTile]) {
   bool ok = true;
+  double tprev = 0.0;
 #pragma unroll
   for (int j = 0; j < kTile; ++j) {
+    double col[kTile];
+    if (j >= 1) {
+#pragma unroll
+      for (int c = j + 1; c < kTile; ++c) col[c] = s_col[(j - 1) & 1][c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const double d = readlane_f64(a[j], j);
     ok = ok && (d > 0.0) && isfinite(d);
     const double inv = rsqrt_nr(d);
+    const double t = a[j] * inv * inv;
+    if (j + 1 < kTile) a[j + 1] -= t * readlane_f64(a[j], j + 1);
+    if (lane < kTile) s_col[j & 1][lane] = a[j];
     if (lane == 0) s_inv[j] = inv;
     a[j] *= inv;
+    __builtin_amdgcn_sched_barrier(0);
+    if (j >= 1) {
 #pragma unroll
-    for (int c = j + 1; c < kTile; ++c) a[c] -= a[j] * readlane_f64(a[j], c);
+      for (int c = j + 1; c < kTile; ++c) {
+        a[c] -= tprev * col[c];
+        asm volatile("" : "+v"(a[c]));  // materialise now: stops LLVM from deferring these updates
+      }
+    }
+    tprev = t;
   }
   return ok;
 }
 
 // x <- x L^-T for the row held by this lane; L^T is read from LDS as s_Lt[c*32 + k] = L[k][c]
-// (uniform addresses: broadcast reads), 1/L[c][c] from s_inv.
+// (uniform addresses: broadcast reads), 1/L[c][c] from s_inv.  The reads of column c+1 are issued
+// before the multiply-adds of column c.
 __device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt, const double* s_inv) {
+  double lt[2][kTile];
+  double iv[2];
+#pragma unroll
+  for (int k = 1; k < kTile; ++k) lt[0][k] = s_Lt[k];
+  iv[0] = s_inv[0];
 #pragma unroll
   for (int c = 0; c < kTile; ++c) {
-    x[c] *= s_inv[c];
+    if (c + 1 < kTile) {
 #pragma unroll
-    for (int k = c + 1; k < kTile; ++k) x[k] -= x[c] * s_Lt[c * kTile + k];
+      for (int k = c + 2; k < kTile; ++k) lt[(c + 1) & 1][k] = s_Lt[(c + 1) * kTile + k];
+      iv[(c + 1) & 1] = s_inv[c + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    x[c] *= iv[c & 1];
+#pragma unroll
+    for (int k = c + 1; k < kTile; ++k) {
+      x[k] -= x[c] * lt[c & 1][k];
+      asm volatile("" : "+v"(x[k]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -143,10 +180,14 @@ __device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt,
 // j+1 are turned into L right away: each of those waves re-derives the updated diagonal tile,
 // factors it in registers and solves its own tile against it.  The wave that owns the diagonal
 // tile also stores L^-T of it (LinvT) for the back substitution.
-__global__ __launch_bounds__(64) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail) {
+int g_dbg_flags = 0;
+extern "C" void mpsfm_debug_set(int f) { g_dbg_flags = f; }
+__global__ __launch_bounds__(64) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg) {
   __shared__ double s_T[kTile][kTile + 1];
+  __shared__ double s_X[kTile][kTile + 1];
   __shared__ double s_Lt[kTile * kTile];
   __shared__ double s_inv[kTile];
+  __shared__ double s_col[2][kTile];
   const int lane = threadIdx.x;
   const int tk = j + 1 + blockIdx.y;
   const int ti = j + 1 + blockIdx.x;
@@ -154,61 +195,64 @@ __global__ __launch_bounds__(64) void k_chol_step(double* A, double* LinvT, int 
   double* C = A + lt_tile(ti, tk) * kTileElems;
   v4d acc[2][2];
   tile_load_acc(C, lane, acc);
-  if (j >= 0) tile_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, acc);
+  if (j >= 0 && !(dbg & 4)) tile_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, acc);
   if (tk != j + 1) {
     tile_store_acc(C, kTile, lane, acc);
     return;
   }
   // ---- panel column j+1 -------------------------------------------------------------------
   const int row = lane & 31;
-  double a[kTile], x[kTile];
-  if (ti == tk) {
+  const bool diag = (ti == tk);
+  if (diag) {
     tile_store_acc(&s_T[0][0], kTile + 1, lane, acc);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < kTile; ++c) a[c] = s_T[row][c];
-#pragma unroll
-    for (int c = 0; c < kTile; ++c) x[c] = (c == row) ? 1.0 : 0.0;  // identity: x L^-T = row of L^-T
   } else {
     v4d dacc[2][2];
     tile_load_acc(A + lt_tile(tk, tk) * kTileElems, lane, dacc);
     if (j >= 0) {
       const double* Lk = A + lt_tile(tk, j) * kTileElems;
-      tile_syrk_sub(Lk, Lk, lane, dacc);
+      if (!(dbg & 4)) tile_syrk_sub(Lk, Lk, lane, dacc);
     }
     tile_store_acc(&s_T[0][0], kTile + 1, lane, dacc);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < kTile; ++c) a[c] = s_T[row][c];
-    __syncthreads();
-    tile_store_acc(&s_T[0][0], kTile + 1, lane, acc);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < kTile; ++c) x[c] = s_T[row][c];
-  }
-  const bool ok = potrf_rows(a, lane, s_inv);
-  if (lane < kTile) {
-#pragma unroll
-    for (int c = 0; c < kTile; ++c) s_Lt[c * kTile + lane] = a[c];
+    tile_store_acc(&s_X[0][0], kTile + 1, lane, acc);
   }
   __syncthreads();
-  trsm_row(x, s_Lt, s_inv);
-  if (ti == tk) {
-    if (!ok && lane == 0) atomicExch(fail, 1);
+  bool ok = true;
+  {
+    // factor the diagonal tile, one row per lane; only L^T and 1/diag survive (in LDS)
+    double a[kTile];
+#pragma unroll
+    for (int c = 0; c < kTile; ++c) a[c] = s_T[row][c];
+    if (!(dbg & 1)) ok = potrf_rows(a, lane, s_inv, s_col);
     if (lane < kTile) {
-      double2* dst = reinterpret_cast<double2*>(C + lane * kTile);
-      double2* dinv = reinterpret_cast<double2*>(LinvT + (size_t)tk * kTileElems + lane * kTile);
 #pragma unroll
-      for (int c = 0; c < kTile; c += 2) {
-        dst[c >> 1] = make_double2(c <= lane ? a[c] : 0.0, c + 1 <= lane ? a[c + 1] : 0.0);
-        dinv[c >> 1] = make_double2(x[c], x[c + 1]);
-      }
+      for (int c = 0; c < kTile; ++c) s_Lt[c * kTile + lane] = a[c];
     }
-  } else if (lane < kTile) {
-    double2* dst = reinterpret_cast<double2*>(C + lane * kTile);
+    if (diag && lane < kTile) {
+      double2* dst = reinterpret_cast<double2*>(C + lane * kTile);
 #pragma unroll
-    for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(x[c], x[c + 1]);
+      for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(c <= lane ? a[c] : 0.0, c + 1 <= lane ? a[c + 1] : 0.0);
+    }
   }
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    double x[kTile];
+    if (diag) {
+#pragma unroll
+      for (int c = 0; c < kTile; ++c) x[c] = (c == row) ? 1.0 : 0.0;  // identity: x L^-T = row of L^-T
+    } else {
+#pragma unroll
+      for (int c = 0; c < kTile; ++c) x[c] = s_X[row][c];
+    }
+    if (!(dbg & 2)) trsm_row(x, s_Lt, s_inv);
+    if (lane < kTile) {
+      double2* dst = diag ? reinterpret_cast<double2*>(LinvT + (size_t)tk * kTileElems + lane * kTile)
+                          : reinterpret_cast<double2*>(C + lane * kTile);
+#pragma unroll
+      for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(x[c], x[c + 1]);
+    }
+  }
+  if (diag && !ok && lane == 0) atomicExch(fail, 1);
 }
 
 // ---- back substitution  y = L^-T z  in groups of kBsG tile rows --------------------------------
@@ -325,7 +369,7 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   for (int j = -1; j <= nt - 2; ++j) {
     const int rows = nt - j;      // ti in [j+1, nt]
     const int cols = (j < 0) ? 1 : nt - 1 - j;  // tk in [j+1, nt-1]; the first step only factors column 0
-    hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(64), 0, s, A, LinvT, nt, j, fail);
+    hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(64), 0, s, A, LinvT, nt, j, fail, g_dbg_flags);
   }
   hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
   for (int t1 = nt; t1 > 0; t1 -= kBsG) {
