@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
           for (int k = 0; k < 3; ++k) atomicAdd(&s_g[lpt * 3 + k], g[k]);
         }
       }
-      if (lcam != (int)kLcamConst) {
+      if (lcam != (int)kLcamConst && !(A.dbg & 1)) {
         const int slot = s_slot[lcam];
         // diag(U)
 #pragma unroll
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     }
 
     // ---- P3b: Schur pairs  S[ci,cj] -= W_i Vinv W_j^T ------------------------------------------
-    for (int e = tid; e < H.npairs; e += kThreads) {
+    for (int e = tid; e < ((A.dbg & 2) ? 0 : H.npairs); e += kThreads) {
       // landmark owning pair e
       int lo = 0, hi = npt;  // s_ppre[lo] <= e < s_ppre[hi]
       while (hi - lo > 1) {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   if (MODE == MODE_FULL) {
     for (int idx = tid; idx < kTileBlocks * 36; idx += kThreads) {
       const double v = s_tile[idx];
-      if (v != 0.0) {
+      if (v != 0.0 && !(A.dbg & 4)) {
         const int blk = idx / 36, el = idx - blk * 36;
         const int li = c_tile_li[blk], lj = c_tile_lj[blk];
         atomicAdd(&A.Sblk[ut_block(s_slot[li], s_slot[lj], A.ncv) * 36 + el], v);

@@ -33,6 +33,7 @@ void launch_assemble(const AssembleArgs&, hipStream_t);
 void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t);
 
 thread_local std::string g_err;
+extern int g_dbg_flags;  // dense_chol.hip: bits 0-7 dense-solve ablations, bits 8-15 track-sweep ablations
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 #define HIP_TRY(expr)                                                                         \
@@ -440,7 +441,7 @@ static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius) {
   a.rec_xy = h->d_rec_xy; a.rec_d = h->d_rec_d; a.rec_m = h->d_rec_m; a.rec_a = h->d_rec_a;
   a.pt_rec_start = h->d_pt_rec_start; a.pt_kv = h->d_pt_kv; a.pt_pair_start = h->d_pt_pair_start;
   a.camtab = h->d_camtab; a.pts = h->d_pts; a.ps = h->d_ps; a.loss = h->loss;
-  a.radius = radius; a.min_diag = h->opt.min_lm_diagonal; a.max_diag = h->opt.max_lm_diagonal; a.ncv = h->ncv;
+  a.radius = radius; a.min_diag = h->opt.min_lm_diagonal; a.max_diag = h->opt.max_lm_diagonal; a.ncv = h->ncv; a.dbg = (g_dbg_flags >> 8) & 0xff;
   a.Sblk = h->d_Sblk; a.gc = h->d_gc; a.wv = h->d_wv; a.diagU = h->d_diagU; a.part = h->d_part; a.diagV = h->d_diagV;
   a.yc = h->d_yc; a.camtab2 = h->d_camtab2; a.pts2 = h->d_pts2; a.part2 = h->d_part2;
   return a;

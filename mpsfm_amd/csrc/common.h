@@ -154,6 +154,7 @@ struct SweepArgs {
   LossParams loss;
   double radius, min_diag, max_diag;
   int32_t ncv;
+  int32_t dbg;  // timing-only ablation switches (0 in production)
   // outputs of the track sweep (accumulated, caller zeroes)
   double* Sblk;    // packed upper block triangle, 36 doubles per block
   double* gc;      // [6 ncv] sum Jc^T r

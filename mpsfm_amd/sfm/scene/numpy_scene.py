@@ -1,0 +1,327 @@
+"""A NumPy scene that exposes the accessor names the reference's Optimizer / MpsfmTriangulator use on
+``MpsfmReconstruction`` and the fork's pycolmap objects (SURVEY.md §8b "Scene accessors"):
+
+  mpsfm_rec.images[imid]            .camera_id .kp_std .cam_from_world(.rotation.quat xyzw, .translation)
+                                    .depth .has_pose .points2D[i].xy
+                                    .get_observation_point2D_idxs() .keypoint_coordinates(idxs)
+                                    .point3D_ids(idxs)
+  mpsfm_rec.rec.cameras[camera_id]  .params [fx fy cx cy] .sx .sy .cam_from_img(xy) .calibration_matrix()
+  mpsfm_rec.points3D[pid]           .xyz .track.length() .track.elements[*].image_id/.point2D_idx
+  mpsfm_rec.obs                     .add_point3D(xyz, track) .delete_point3D(pid)
+                                    .find_small_angle_points_mask(min_angle_deg, ids)
+  mpsfm_rec.point_covs.data         {pid: 3x3}
+  mpsfm_rec.project_image_3d_points(imid, ids) / point3D_coordinates(ids) / registered_images
+
+It lets the host layer be exercised without pycolmap (not installable offline); with pycolmap
+present the same Optimizer works on the real objects because it only uses these names.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ...synthetic import R_from_quat, quat_from_R
+from .priorutils import PriorUtils
+
+INVALID_POINT3D = 18446744073709551615  # pycolmap's kInvalidPoint3DId (reference triangulator.py:109)
+
+
+class Rotation3d:
+    def __init__(self, quat_xyzw):
+        self.quat = np.array(quat_xyzw, dtype=np.float64)
+
+    def matrix(self):
+        return R_from_quat(self.quat)[0]
+
+
+class Rigid3d:
+    """cam_from_world: x_cam = R x_world + t."""
+
+    def __init__(self, quat_xyzw, translation):
+        self.rotation = Rotation3d(quat_xyzw)
+        self.translation = np.array(translation, dtype=np.float64)
+
+    def matrix(self):
+        return np.concatenate([self.rotation.matrix(), self.translation[:, None]], axis=1)
+
+    def inverse(self):
+        R = self.rotation.matrix()
+        return Rigid3d(quat_from_R(R.T[None])[0], -R.T @ self.translation)
+
+    def __mul__(self, pts):
+        pts = np.asarray(pts, dtype=np.float64)
+        return pts @ self.rotation.matrix().T + self.translation
+
+
+class NumpyCamera:
+    def __init__(self, camera_id, params, width, height, map_width, map_height):
+        self.camera_id = camera_id
+        self.params = np.array(params, dtype=np.float64)  # PINHOLE fx fy cx cy
+        self.width, self.height = width, height
+        self.sx, self.sy = map_width / width, map_height / height
+
+    focal_length_x = property(lambda s: s.params[0])
+    focal_length_y = property(lambda s: s.params[1])
+    principal_point_x = property(lambda s: s.params[2])
+    principal_point_y = property(lambda s: s.params[3])
+
+    def calibration_matrix(self):
+        fx, fy, cx, cy = self.params
+        return np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+
+    def cam_from_img(self, xy):
+        xy = np.atleast_2d(np.asarray(xy, dtype=np.float64))
+        return (xy - self.params[2:4]) / self.params[0:2]
+
+
+@dataclass
+class TrackElement:
+    image_id: int
+    point2D_idx: int
+
+
+class Track:
+    def __init__(self):
+        self.elements: list[TrackElement] = []
+
+    def add_element(self, image_id, point2D_idx):
+        self.elements.append(TrackElement(int(image_id), int(point2D_idx)))
+
+    def length(self):
+        return len(self.elements)
+
+
+class NumpyPoint3D:
+    def __init__(self, xyz, track=None):
+        self.xyz = np.array(xyz, dtype=np.float64)
+        self.track = track if track is not None else Track()
+
+
+class Point2D:
+    __slots__ = ("_img", "_i")
+
+    def __init__(self, img, i):
+        self._img, self._i = img, i
+
+    @property
+    def xy(self):
+        return self._img.kps[self._i]
+
+    @property
+    def point3D_id(self):
+        return int(self._img.kp_point3D[self._i])
+
+    def has_point3D(self):
+        return self.point3D_id != INVALID_POINT3D
+
+
+class _Points2DView:
+    def __init__(self, img):
+        self._img = img
+
+    def __getitem__(self, i):
+        return Point2D(self._img, int(i))
+
+    def __len__(self):
+        return self._img.kps.shape[0]
+
+    def __iter__(self):
+        return (Point2D(self._img, i) for i in range(len(self)))
+
+
+class NumpyDepth(PriorUtils):
+    """Prior depth map + validity + variance with the attribute names of the reference's Depth
+    (mpsfm/sfm/scene/image/depth.py:34-130)."""
+
+    def __init__(self, data_prior, uncertainty, valid, camera, kps):
+        self.data_prior = np.array(data_prior, dtype=np.float64)
+        self.data = self.data_prior.copy()  # the integrated ("update") map starts as the prior
+        self.uncertainty = np.array(uncertainty, dtype=np.float64)
+        self.valid = np.array(valid, dtype=np.float64)
+        self.camera = camera
+        self.kps = kps
+        self.scale = 1.0
+        self.activated = True
+        self.uncertainty_update = self.uncertainty_at_kps(kps)  # depth.py:130
+
+
+class NumpyImage:
+    def __init__(self, image_id, camera_id, cam_from_world, kps, kp_std=1.0, depth=None):
+        self.image_id, self.camera_id = image_id, camera_id
+        self.cam_from_world = cam_from_world
+        self.kps = np.array(kps, dtype=np.float64).reshape(-1, 2)
+        self.kp_point3D = np.full(self.kps.shape[0], INVALID_POINT3D, dtype=np.uint64)
+        self.kp_std = kp_std
+        self.depth = depth
+        self.has_pose = True
+        self.points2D = _Points2DView(self)
+
+    def get_observation_point2D_idxs(self):
+        return np.flatnonzero(self.kp_point3D != INVALID_POINT3D)
+
+    def keypoint_coordinates(self, idxs):
+        return self.kps[np.asarray(idxs, dtype=np.int64)]
+
+    def point3D_ids(self, idxs=None):
+        if idxs is None:
+            return [int(v) for v in self.kp_point3D]
+        return [int(v) for v in self.kp_point3D[np.asarray(idxs, dtype=np.int64)]]
+
+
+class PointCovs:
+    """reference mpsfm/sfm/scene/pointcov.py:4-20"""
+
+    def __init__(self):
+        self.data = {}
+
+    def points_zvars(self, image, p3d_ids=None):
+        if p3d_ids is None:
+            p3d_ids = [p.point3D_id for p in image.points2D if p.has_point3D()]
+        R = image.cam_from_world.rotation.matrix()
+        data = np.array([self.data[p] for p in p3d_ids])
+        return p3d_ids, np.einsum("ij,njk,lk->nil", R, data, R)[:, 2, 2]
+
+
+class _Rec:
+    def __init__(self):
+        self.cameras = {}
+
+
+class ObservationManager:
+    def __init__(self, scene):
+        self.scene = scene
+
+    def add_point3D(self, xyz, track):
+        s = self.scene
+        pid = s._next_point3D_id
+        s._next_point3D_id += 1
+        s.points3D[pid] = NumpyPoint3D(xyz, track)
+        for el in track.elements:
+            s.images[el.image_id].kp_point3D[el.point2D_idx] = pid
+        return pid
+
+    def delete_point3D(self, pid):
+        s = self.scene
+        for el in s.points3D[pid].track.elements:
+            s.images[el.image_id].kp_point3D[el.point2D_idx] = INVALID_POINT3D
+        del s.points3D[pid]
+        s.point_covs.data.pop(pid, None)
+
+    def find_small_angle_points_mask(self, min_angle_deg, point3D_ids):
+        """True where the largest pairwise triangulation angle of the track is below min_angle
+        (the fork's ObservationManager.find_small_angle_points_mask, reference points3D_utils.py:64-71)."""
+        from ..mapper.triangulator import track_quality
+
+        ang, _, _ = track_quality(self.scene, list(point3D_ids))
+        return ang < np.deg2rad(min_angle_deg)
+
+
+class NumpyReconstruction:
+    def __init__(self):
+        self.images: dict[int, NumpyImage] = {}
+        self.points3D: dict[int, NumpyPoint3D] = {}
+        self.rec = _Rec()
+        self.obs = ObservationManager(self)
+        self.point_covs = PointCovs()
+        self._next_point3D_id = 1
+
+    @property
+    def registered_images(self):
+        return {i: im for i, im in self.images.items() if im.has_pose}
+
+    def point3D_coordinates(self, ids):
+        return np.array([self.points3D[int(i)].xyz for i in ids], dtype=np.float64).reshape(-1, 3)
+
+    def project_image_3d_points(self, imid, pts3dids=None):
+        """(pts2dids, pts3dids, kps, depth, success) — reference points3D_utils.py:9-25 + geometry.py:13-19."""
+        image = self.images[imid]
+        pts2dids = None
+        if pts3dids is None:
+            pts2dids = image.get_observation_point2D_idxs()
+            pts3dids = image.point3D_ids(pts2dids)
+            if len(pts3dids) == 0:
+                return None, None, None, None, False
+        X = self.point3D_coordinates(pts3dids)
+        Xc = image.cam_from_world * X
+        depth = Xc[:, 2].copy()
+        K = self.rec.cameras[image.camera_id].calibration_matrix()
+        kps = (Xc / depth[:, None]) @ K.T
+        return pts2dids, pts3dids, kps[:, :2], depth, True
+
+    def find_points3D_with_small_triangulation_angle(self, min_angle, point3D_ids):
+        return np.array(self.obs.find_small_angle_points_mask(float(min_angle), point3D_ids))
+
+    def find_local_bundle_ids(self, imid, num_images):
+        """Images sharing the most 3-D points with imid (stand-in for COLMAP's FindLocalBundle)."""
+        mine = set(self.images[imid].point3D_ids(self.images[imid].get_observation_point2D_idxs()))
+        scores = []
+        for other, im in self.images.items():
+            if other == imid or not im.has_pose:
+                continue
+            shared = len(mine & set(im.point3D_ids(im.get_observation_point2D_idxs())))
+            if shared:
+                scores.append((-shared, other))
+        return [o for _, o in sorted(scores)[:num_images]]
+
+
+def scene_from_problem(prob, truth=None, map_size=(129, 97), image_size=(1600.0, 1200.0), seed=0,
+                       prior_noise=0.0263, first_image_id=1):
+    """Builds a NumpyReconstruction from a synthetic BAProblem (mpsfm_amd.synthetic.make_scene):
+    one keypoint per observation, per-image prior depth maps splatted from the true camera-frame
+    depths (so the sampled priors are roughly right), variance map from the reference's model."""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(seed)
+    scene = NumpyReconstruction()
+    W, H = map_size
+    n_cams = prob.n_cams
+    tq = truth["cam_quat"] if truth is not None else prob.cam_quat
+    tt = truth["cam_t"] if truth is not None else prob.cam_t
+    tX = truth["pts"] if truth is not None else prob.pts
+    for k in range(prob.cam_intr.shape[0]):
+        scene.rec.cameras[k] = NumpyCamera(k, prob.cam_intr[k], image_size[0], image_size[1], W, H)
+    order = np.argsort(prob.obs_cam, kind="stable")
+    starts = np.searchsorted(prob.obs_cam[order], np.arange(n_cams + 1))
+    Rt = R_from_quat(tq)
+    imids = [first_image_id + c for c in range(n_cams)]
+    for c in range(n_cams):
+        idx = order[starts[c]:starts[c + 1]]
+        kps = prob.obs_xy[idx]
+        cam = scene.rec.cameras[int(prob.cam_intr_idx[c])]
+        ztrue = (tX[prob.obs_pt[idx]] @ Rt[c].T + tt[c])[:, 2]
+        depth = None
+        if len(idx) >= 3:
+            gy, gx = np.mgrid[0:H, 0:W]
+            tree = cKDTree(np.stack([kps[:, 0] * cam.sx, kps[:, 1] * cam.sy], 1))
+            _, nn = tree.query(np.stack([gx.ravel(), gy.ravel()], 1), k=min(3, len(idx)))
+            nn = nn.reshape(H * W, -1)
+            dmap = ztrue[nn].mean(axis=1).reshape(H, W) * np.exp(rng.normal(0, prior_noise, (H, W)))
+            var = np.maximum((prior_noise * dmap) ** 2, 0.02**2)
+            valid = (rng.uniform(size=(H, W)) > 0.03).astype(np.float64)
+            depth = NumpyDepth(dmap, var, valid, cam, kps)
+        img = NumpyImage(imids[c], int(prob.cam_intr_idx[c]), Rigid3d(prob.cam_quat[c], prob.cam_t[c]), kps, 1.0, depth)
+        if depth is None:
+            img.depth = NumpyDepth(np.ones((H, W)), np.ones((H, W)), np.zeros((H, W)), cam, kps)
+            img.depth.activated = False
+        img._obs_index = idx
+        scene.images[imids[c]] = img
+    # points and tracks
+    pt_order = np.argsort(prob.obs_pt, kind="stable")
+    pstarts = np.searchsorted(prob.obs_pt[pt_order], np.arange(prob.n_pts + 1))
+    local_idx = np.empty(prob.n_obs, dtype=np.int64)
+    for c in range(n_cams):
+        idx = order[starts[c]:starts[c + 1]]
+        local_idx[idx] = np.arange(len(idx))
+    pid_of = {}
+    for p in range(prob.n_pts):
+        obs = pt_order[pstarts[p]:pstarts[p + 1]]
+        if len(obs) == 0:
+            continue
+        tr = Track()
+        for o in obs:
+            tr.add_element(imids[int(prob.obs_cam[o])], int(local_idx[o]))
+        pid_of[p] = scene.obs.add_point3D(prob.pts[p], tr)
+    scene._pid_of_problem_point = pid_of
+    return scene

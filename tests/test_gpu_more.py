@@ -1,0 +1,234 @@
+"""GPU parity tests beyond the core solve: the Optimizer shim end to end, point covariances,
+triangulation numerics, landmark sharding on device buffers, edge cases and full-size properties."""
+
+import threading
+
+import numpy as np
+import pytest
+
+from mpsfm_amd import capi
+from mpsfm_amd.dist import shard_problem
+from mpsfm_amd.problem import BAProblem, Tracks
+from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
+from mpsfm_amd.sfm.mapper.triangulator import MpsfmTriangulator, track_quality, triangulate_points
+from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+from mpsfm_amd.synthetic import make_config, make_scene
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleBackend:
+    def solve(self, prob):
+        return O.solve(prob)
+
+    def point_covs(self, prob):
+        return O.point_covs(prob)
+
+
+def _bundle(sc):
+    return {"optim_ids": set(sc.images.keys()), "pts3D": set(sc.points3D.keys()), "constpoints": set()}
+
+
+@pytest.mark.parametrize("mode", ["global", "local"])
+def test_optimizer_shim_matches_oracle_backend(mode):
+    prob, truth = make_scene(8, 400, True, seed=21)
+    sc_g, sc_o = scene_from_problem(prob, truth, seed=3), scene_from_problem(prob, truth, seed=3)
+    og, oo = Optimizer({}, sc_g, None), Optimizer({}, sc_o, None, backend=OracleBackend())
+    if mode == "global":
+        bg, bo = _bundle(sc_g), _bundle(sc_o)
+    else:
+        ids = sorted(sc_g.images)
+        pts = set(sc_g.images[ids[3]].point3D_ids(sc_g.images[ids[3]].get_observation_point2D_idxs()))
+        bg = {"ref_id": ids[3], "optim_ids": {ids[2], ids[3], ids[4]}, "pts3D": pts, "constpoints": set()}
+        bo = dict(bg)
+    for o, b in ((og, bg), (oo, bo)):
+        o.calculate_point_covs(b)
+        o.update_truncation_multiplier(list(b["optim_ids"]))
+    assert og.truncation_multiplier == pytest.approx(oo.truncation_multiplier, rel=1e-12)
+    rg, _ = og.ba(bg, mode=mode, allow_scale_filter=True)
+    ro, _ = oo.ba(bo, mode=mode, allow_scale_filter=True)
+    assert rg.summary["final_cost"] == pytest.approx(ro.summary["final_cost"], rel=1e-8)
+    for i in sc_g.images:
+        np.testing.assert_allclose(sc_g.images[i].cam_from_world.translation, sc_o.images[i].cam_from_world.translation, atol=1e-6)
+        np.testing.assert_allclose(np.abs(sc_g.images[i].cam_from_world.rotation.quat @ sc_o.images[i].cam_from_world.rotation.quat), 1, atol=1e-10)
+    for p in sc_g.points3D:
+        np.testing.assert_allclose(sc_g.points3D[p].xyz, sc_o.points3D[p].xyz, atol=1e-6)
+    for p in bg["pts3D"]:
+        np.testing.assert_allclose(sc_g.point_covs.data[p], sc_o.point_covs.data[p], rtol=1e-9, atol=1e-18)
+    rg, _ = og.refine_3d_points(bg, depth_type="prior")
+    ro, _ = oo.refine_3d_points(bo, depth_type="prior")
+    assert rg.summary["final_cost"] == pytest.approx(ro.summary["final_cost"], rel=1e-9)
+
+
+def test_point_covs_match_oracle():
+    prob, _ = make_scene(12, 2000, False, seed=7)
+    prob.reproj_loss_magnitude = 0.25
+    c_g, c_o = capi.point_covs(prob), O.point_covs(prob)
+    np.testing.assert_allclose(c_g, c_o, rtol=1e-9, atol=1e-18)
+    assert np.all(np.linalg.eigvalsh(c_g) > 0)
+
+
+def _tracks_of(prob, truth):
+    order = np.argsort(prob.obs_pt, kind="stable")
+    start = np.searchsorted(prob.obs_pt[order], np.arange(prob.n_pts + 1))
+    return Tracks(truth["cam_quat"], truth["cam_t"], prob.cam_intr, prob.cam_intr_idx, start, prob.obs_cam[order], prob.obs_xy[order])
+
+
+def test_triangulation_numerics_match_oracle_and_truth():
+    prob, truth = make_scene(15, 3000, False, seed=9, outlier_frac=0.0)
+    tr = _tracks_of(prob, truth)
+    x_g, x_o = capi.triangulate_tracks(tr), O.triangulate_tracks(tr)
+    np.testing.assert_allclose(x_g, x_o, rtol=0, atol=1e-9)
+    assert np.median(np.linalg.norm(x_g - truth["pts"], axis=1)) < 0.05  # 1 px noise, fp16-rounded pixels
+    a_g, e_g, f_g = capi.filter_tracks(tr, x_g)
+    a_o, e_o, f_o = O.filter_tracks(tr, x_g)
+    np.testing.assert_allclose(a_g, a_o, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(e_g, e_o, rtol=1e-10, atol=1e-12)
+    np.testing.assert_array_equal(f_g, f_o)
+    assert f_g.all() and 0 < a_g.max() <= np.pi / 2
+
+
+def test_triangulator_lifts_low_parallax_points():
+    prob, truth = make_scene(6, 200, True, seed=11)
+    sc = scene_from_problem(prob, truth, seed=1)
+    tri = MpsfmTriangulator({"colmap_options": {}}, sc, None)
+    ids = list(sc.points3D)
+    ang, err, front = track_quality(sc, ids)
+    assert ang.shape == (len(ids),) and front.all()
+    thr = np.rad2deg(np.median(ang))
+    n_before = len(sc.points3D)
+    new_ids = tri.lift_low_parallax(ids, thr)
+    assert 0 < len(new_ids) <= (ang < np.deg2rad(thr)).sum() and len(sc.points3D) <= n_before
+    for pid in new_ids:  # a lifted point sits on the viewing ray of its first activated image at the sampled depth
+        el = sc.points3D[pid].track.elements[0]
+        im = sc.images[el.image_id]
+        z = (im.cam_from_world * sc.points3D[pid].xyz[None])[0, 2]
+        assert z > 0
+    xyz = triangulate_points(sc, ids[:5] if all(i in sc.points3D for i in ids[:5]) else list(sc.points3D)[:5])
+    assert xyz.shape == (5, 3)
+    with pytest.raises(NotImplementedError):
+        tri.complete_and_merge_all_tracks()
+
+
+def test_landmark_sharded_solve_on_device_buffers():
+    """Two shards on one GPU, each with its own handle and thread; the hook sums the device
+    buffers with torch (stands in for the RCCL all-reduce across ranks)."""
+    import ctypes as C
+
+    import torch
+
+    from mpsfm_amd.dist import _DevView
+    from mpsfm_amd.problem import ALLREDUCE_FN
+
+    prob, _ = make_scene(12, 1500, True, seed=13)
+    ref = prob.copy()
+    s_ref = capi.ba_solve(ref)
+    world = 2
+    bar = threading.Barrier(world)
+    slots, results = [None] * world, [None] * world
+    lock = threading.Lock()
+
+    def make_hook(rank):
+        def cb(user, buf, count, on_device, stream):
+            ptr = C.addressof(buf.contents)
+            if on_device:
+                torch.cuda.synchronize()
+                t = torch.as_tensor(_DevView(ptr, int(count)), device="cuda")
+            else:
+                t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(int(count),)))
+            slots[rank] = t
+            bar.wait()
+            total = slots[0].clone().to(t.device) + slots[1].clone().to(t.device)
+            bar.wait()
+            t.copy_(total)
+            if on_device:
+                torch.cuda.synchronize()
+            bar.wait()
+            return 0
+        return ALLREDUCE_FN(cb)
+
+    shards = [shard_problem(prob, r, world) for r in range(world)]
+
+    def run(rank):
+        fn = make_hook(rank)
+        opts = capi.default_options()
+        opts.allreduce = fn
+        results[rank] = capi.ba_solve(shards[rank][0], opts)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=240) for t in th]
+    assert all(r is not None for r in results)
+    for r in range(world):
+        assert results[r]["num_iterations"] == s_ref["num_iterations"]
+        assert results[r]["final_cost"] == pytest.approx(s_ref["final_cost"], rel=1e-9)
+        lo, hi = shards[r][1]
+        np.testing.assert_allclose(shards[r][0].pts, ref.pts[lo:hi], atol=1e-7)
+        np.testing.assert_allclose(shards[r][0].cam_t, ref.cam_t, atol=1e-7)
+
+
+def test_edge_cases():
+    base, _ = make_scene(4, 60, True, seed=17)
+    # no residual blocks at all
+    empty = BAProblem(base.cam_quat, base.cam_t, base.pts, base.cam_intr, base.cam_intr_idx, base.pose_const, base.pt_const,
+                      np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2)))
+    s = capi.ba_solve(empty)
+    assert s["termination"] == "no_variables" and s["final_cost"] == 0.0
+    # everything constant: cost only, equals the oracle's
+    allc = base.copy()
+    allc.pose_const[:] = 1
+    allc.pt_const[:] = 1
+    sg, so = capi.ba_solve(allc.copy()), O.solve(allc.copy())
+    assert sg["termination"] == "no_variables" and sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-12)
+    # one free camera, constant points (pose refinement); unreferenced points stay untouched
+    pose = base.copy()
+    pose.pt_const[:] = 1
+    pose.pose_const[:] = [1, 1, 1, 0]
+    pose.gauge_axis_cam = -1
+    pg, po = pose.copy(), pose.copy()
+    sg, so = capi.ba_solve(pg), O.solve(po)
+    assert sg["reduced_dim"] == 6 and sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-9)
+    np.testing.assert_array_equal(pg.pts, pose.pts)
+    # a point behind the camera in a log-depth block: the initial point cannot be evaluated
+    bad = base.copy()
+    bad.pts[int(bad.dobs_pt[0])] = -50 * bad.pts[int(bad.dobs_pt[0])] - 100.0
+    with pytest.raises(capi.MpsfmHipError) as e:
+        capi.ba_solve(bad)
+    assert e.value.code == -5
+    # a track longer than one chunk is refused loudly (not silently mishandled)
+    long_prob, _ = make_scene(260, 3, False, seed=1, max_track=260)
+    long_prob.obs_cam = np.concatenate([long_prob.obs_cam, np.arange(260, dtype=np.int32)])
+    long_prob.obs_pt = np.concatenate([long_prob.obs_pt, np.zeros(260, np.int32)])
+    long_prob.obs_xy = np.concatenate([long_prob.obs_xy, np.full((260, 2), 500.0)])
+    with pytest.raises(capi.MpsfmHipError) as e:
+        capi.ba_solve(long_prob)
+    assert e.value.code == -6
+
+
+def test_full_size_properties_c3():
+    """BASELINE config C3 (200 cameras / 150k landmarks): size-independent properties."""
+    prob, _ = make_config("C3")
+    with capi.BAHandle(prob) as h:
+        c0 = sum(h.eval_cost())
+        s1 = h.solve()
+        c1 = sum(h.eval_cost())
+        assert s1["initial_cost"] == pytest.approx(c0, rel=1e-10)
+        assert s1["final_cost"] == pytest.approx(c1, rel=1e-10)          # summary cost is the cost of the returned state
+        tc = np.array(s1["trace_cost"])
+        assert np.all(np.diff(tc) <= 1e-9 * tc[:-1]) and s1["final_cost"] < 0.15 * s1["initial_cost"]
+        assert s1["termination"] == "function_tolerance" and s1["num_iterations"] <= 50
+        assert s1["num_residual_blocks"] == prob.n_obs + prob.n_dobs
+        h.reset_state()
+        s2 = h.solve()                                                    # reset + solve again: same trajectory
+        assert s2["num_iterations"] == s1["num_iterations"]
+        assert s2["final_cost"] == pytest.approx(s1["final_cost"], rel=1e-10)
+        h.get_state()
+        # gauge: camera 0 untouched, camera 1 keeps its x translation
+        ref, _ = make_config("C3")
+        np.testing.assert_array_equal(prob.cam_quat[0], ref.cam_quat[0])
+        assert prob.cam_t[1, 0] == ref.cam_t[1, 0]
+        # re-solving from the optimum stops at once
+        h.set_state(prob)
+        s3 = h.solve()
+        assert s3["num_iterations"] <= 2 and s3["final_cost"] <= s1["final_cost"] * (1 + 1e-9)
