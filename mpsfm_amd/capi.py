@@ -40,6 +40,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MpsfmHipError(-2, f"{LIB_PATH} is missing: run `python -m mpsfm_amd.build` (hipcc, gfx950)")
+        try:
+            # torch wheels bundle their own libamdhip64; if ours (linked against /opt/rocm) is loaded
+            # first the process ends up with two HIP runtimes and torch.cuda reports no devices.
+            # Importing torch first makes its runtime the process-wide one (same soname).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.mpsfm_last_error.restype = C.c_char_p
         L.mpsfm_ba_destroy.restype = None

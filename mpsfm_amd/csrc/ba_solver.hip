@@ -611,7 +611,8 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     x_cost = sc[U_X_COST];
     const bool x_bad = sc[U_X_BAD] > 0.0;  // residual not evaluable or a landmark block not PD
     if (iter == 1) {
-      if (!std::isfinite(x_cost)) return finish(fail(MPSFM_ENUMERIC, "initial cost is not finite"));
+      if (!std::isfinite(x_cost) || x_bad)
+        return finish(fail(MPSFM_ENUMERIC, "the initial point cannot be evaluated (non-finite residual or depth <= 0 in a log-depth block)"));
       sum->initial_cost = x_cost + fixed;
       cur_cost = x_cost;
       trace(x_cost + fixed, radius, 1);
