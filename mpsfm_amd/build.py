@@ -34,6 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("MPSFM_EXTRA_FLAGS", "").split()
     procs = []
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))

@@ -132,62 +132,54 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// decode q in [0, k(k+1)/2) -> (i, j), i <= j < k, row-major upper triangle
-__device__ __forceinline__ void tri_decode(int q, int k, int& i, int& j) {
-  const double b = 2.0 * k + 1.0;
-  int ii = (int)((b - sqrt(b * b - 8.0 * (double)q)) * 0.5);
-  if (ii < 0) ii = 0;
-  if (ii > k - 1) ii = k - 1;
-  // row start(i) = i*k - i(i-1)/2
-  while (ii > 0 && ii * k - (ii * (ii - 1)) / 2 > q) --ii;
-  while ((ii + 1) * k - ((ii + 1) * ii) / 2 <= q) ++ii;
-  i = ii;
-  j = q - (ii * k - (ii * (ii - 1)) / 2) + ii;
-}
-
-__constant__ uint8_t c_tile_li[kTileBlocks];
-__constant__ uint8_t c_tile_lj[kTileBlocks];
-
 enum { MODE_FULL = 0, MODE_DIAG = 1 };
 
+// Track sweep.  One workgroup per chunk of landmarks:
+//   P1  one thread per merged record: residuals, analytic Jacobians, robust weights; V_p / g_p
+//       (ds_add_f64 per landmark), U_c / g_c / diag U (ds_add_f64 per local camera), W = Jc^T Jp to LDS
+//   P2  one thread per landmark: (V + D)^-1 and (V + D)^-1 g_p
+//   P3a rhs part  sum_p W Vinv g_p  per camera
+//   P3b Schur pairs, block-major: the chunk's pairs are pre-sorted (at problem creation) by the 6x6
+//       destination block of S; six lanes own one block (a row each), sum its pairs in registers
+//       and issue ONE global_atomic_add_f64 per block element.  No LDS atomics on this path.
+//   P4  flush the per-camera LDS accumulators, write the chunk partials
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
-  __shared__ double s_tile[kTileBlocks * 36];
   __shared__ double s_W[kObsMax * kWStride];
   __shared__ double s_V[kPtsMax * 6];
   __shared__ double s_g[kPtsMax * 3];
+  __shared__ double s_U[kTileCams * 21];
   __shared__ double s_gc[kTileCams * 6];
   __shared__ double s_wv[kTileCams * 6];
   __shared__ double s_du[kTileCams * 6];
   __shared__ int32_t s_slot[kLocalCamsMax];
-  __shared__ int32_t s_prs[kPtsMax + 1];   // record start (chunk-relative) per landmark
-  __shared__ int32_t s_ppre[kPtsMax + 1];  // pair prefix per landmark
   __shared__ double s_red[3 * (kThreads / 64)];
+  __shared__ double s_stage[(kThreads / kPairGroup) * 36];
+  __shared__ uint32_t s_ents[kEntStage];
 
   const int tid = threadIdx.x;
   const ChunkHdr H = A.chunks[blockIdx.x];
   const int nrec = H.nrec, npt = H.npt, ncam = H.ncam;
 
   // ---- P0: clear accumulators, stage chunk tables -----------------------------------------
-  if (MODE == MODE_FULL) {
-    for (int i = tid; i < kTileBlocks * 36; i += kThreads) s_tile[i] = 0.0;
-  }
   for (int i = tid; i < kPtsMax * 6; i += kThreads) s_V[i] = 0.0;
   for (int i = tid; i < kPtsMax * 3; i += kThreads) s_g[i] = 0.0;
+  for (int i = tid; i < kTileCams * 21; i += kThreads) s_U[i] = 0.0;
   if (tid < kTileCams * 6) { s_gc[tid] = 0.0; s_wv[tid] = 0.0; s_du[tid] = 0.0; }
   if (tid < ncam) s_slot[tid] = A.chunk_cams[H.cam0 + tid];
-  if (tid <= npt) {
-    s_prs[tid] = A.pt_rec_start[H.pt0 + tid] - H.rec0;
-    s_ppre[tid] = (tid < npt) ? A.pt_pair_start[H.pt0 + tid] : H.npairs;
-  }
+  const bool ents_in_lds = (H.nent <= kEntStage);
+  if (MODE == MODE_FULL && ents_in_lds)
+    for (int i = tid; i < H.nent; i += kThreads) s_ents[i] = A.ents[H.ent0 + i];
   __syncthreads();
 
   // ---- P1: per-record residual / Jacobian, J^T J blocks ------------------------------------
   double my_cost = 0.0;
   int my_bad = 0;
+  uint32_t my_meta = 0;
   if (tid < nrec) {
     const int rix = H.rec0 + tid;
     const uint32_t meta = A.rec_meta[rix];
+    my_meta = meta;
     const int cam = A.rec_cam[rix];
     const int lcam = meta & 0xff;
     const int lpt = (meta >> 8) & 0xff;
@@ -228,18 +220,19 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
           else atomicAdd(&A.diagU[(size_t)slot * 6 + i], du);
         }
         if (MODE == MODE_FULL) {
-          // g_c and the upper triangle of U_c
-          double* dstU = (lcam < kTileCams) ? &s_tile[(lcam * kTileCams - (lcam * (lcam - 1)) / 2) * 36]
-                                            : &A.Sblk[ut_block(slot, slot, A.ncv) * 36];
+          // g_c and the upper triangle of U_c (21 values, packed row-major a <= b)
+          double* gS = &A.Sblk[ut_block(slot, slot, A.ncv) * 36];
+          int u = 0;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
             const double gci = L.Jc[i] * L.r[0] + L.Jc[6 + i] * L.r[1] + L.Jc[12 + i] * L.r[2];
             if (lcam < kTileCams) atomicAdd(&s_gc[lcam * 6 + i], gci);
             else atomicAdd(&A.gc[(size_t)slot * 6 + i], gci);
 #pragma unroll
-            for (int j = i; j < 6; ++j) {
+            for (int j = i; j < 6; ++j, ++u) {
               const double uij = L.Jc[i] * L.Jc[j] + L.Jc[6 + i] * L.Jc[6 + j] + L.Jc[12 + i] * L.Jc[12 + j];
-              atomicAdd(&dstU[i * 6 + j], uij);
+              if (lcam < kTileCams) atomicAdd(&s_U[lcam * 21 + u], uij);
+              else atomicAdd(&gS[i * 6 + j], uij);
             }
           }
           // W = Jc^T Jp (6x3) stays in LDS
@@ -291,9 +284,8 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 
     // ---- P3a: rhs part  sum_p W Vinv g_p ------------------------------------------------------
     if (tid < nrec) {
-      const uint32_t meta = A.rec_meta[H.rec0 + tid];
-      const int lcam = meta & 0xff;
-      const int lpt = (meta >> 8) & 0xff;
+      const int lcam = my_meta & 0xff;
+      const int lpt = (my_meta >> 8) & 0xff;
       if (lcam != (int)kLcamConst && A.pt_kv[H.pt0 + lpt] != 0xffff) {
         const double* w = &s_W[tid * kWStride];
         const double v0 = s_g[lpt * 3], v1 = s_g[lpt * 3 + 1], v2 = s_g[lpt * 3 + 2];
@@ -307,82 +299,73 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       }
     }
 
-    // ---- P3b: Schur pairs  S[ci,cj] -= W_i Vinv W_j^T ------------------------------------------
-    for (int e = tid; e < ((A.dbg & 2) ? 0 : H.npairs); e += kThreads) {
-      // landmark owning pair e
-      int lo = 0, hi = npt;  // s_ppre[lo] <= e < s_ppre[hi]
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_ppre[mid] <= e) lo = mid; else hi = mid;
-      }
-      const int lpt = lo;
-      const int kv = A.pt_kv[H.pt0 + lpt];
-      int i, j;
-      tri_decode(e - s_ppre[lpt], kv, i, j);
-      const int ri = s_prs[lpt] + i, rj = s_prs[lpt] + j;
-      const int li = A.rec_meta[H.rec0 + ri] & 0xff, lj = A.rec_meta[H.rec0 + rj] & 0xff;
-      double Vi[6];
+    // ---- P3b: Schur pairs, block-major:  S[ci,cj] -= sum_pairs (W_i Vinv) W_j^T ------------------
+    // Rounds of kGroups blocks: six lanes sum one block in registers, park it in LDS, then the whole
+    // workgroup flushes the round with lanes running along the 36 contiguous doubles of a block
+    // (the access shape global atomics want).
+    {
+      constexpr int kGroups = kThreads / kPairGroup;
+      const int grp = tid / kPairGroup, row = tid - grp * kPairGroup;
+      const int nblk = (A.dbg & 2) ? 0 : H.nblk;
+      for (int b0 = 0; b0 < nblk; b0 += kGroups) {
+        const int b = b0 + grp;
+        if (grp < kGroups && b < nblk) {
+          // entry offsets are chunk-relative
+          int e = A.blk_ent_start[H.blk0 + blockIdx.x + b];
+          const int e1 = A.blk_ent_start[H.blk0 + blockIdx.x + b + 1];
+          const uint32_t* ep = ents_in_lds ? s_ents : (A.ents + H.ent0);
+          double acc[6] = {0, 0, 0, 0, 0, 0};
+          uint32_t ent = (e < e1) ? ep[e] : 0u;
+          while (e < e1) {
+            const uint32_t cur = ent;
+            ++e;
+            if (e < e1) ent = ep[e];  // fetch the next pair while this one is processed
+            const int ri = cur & 0xff, rj = (cur >> 8) & 0xff, lpt = (cur >> 16) & 0xff;
+            const double* wi = &s_W[ri * kWStride + row * 3];
+            double Vi[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Vi[k] = s_V[lpt * 6 + k];
-      double Y[18], Wj[18];
-      {
-        const double* wi = &s_W[ri * kWStride];
+            for (int k = 0; k < 6; ++k) Vi[k] = s_V[lpt * 6 + k];
+            double y[3];
+            sym3_mul(Vi, wi[0], wi[1], wi[2], y);
+            const double* wj = &s_W[rj * kWStride];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) sym3_mul(Vi, wi[a * 3], wi[a * 3 + 1], wi[a * 3 + 2], &Y[a * 3]);
-        const double* wj = &s_W[rj * kWStride];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) Wj[k] = wj[k];
-      }
-      const bool in_tile = (lj < kTileCams);
-      double* dst = in_tile ? &s_tile[(li * kTileCams - (li * (li - 1)) / 2 + (lj - li)) * 36]
-                            : &A.Sblk[ut_block(s_slot[li], s_slot[lj], A.ncv) * 36];
-      if (li != lj) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            const double v = Y[a * 3] * Wj[b * 3] + Y[a * 3 + 1] * Wj[b * 3 + 1] + Y[a * 3 + 2] * Wj[b * 3 + 2];
-            atomicAdd(&dst[a * 6 + b], -v);
+            for (int bb = 0; bb < 6; ++bb) acc[bb] += y[0] * wj[bb * 3] + y[1] * wj[bb * 3 + 1] + y[2] * wj[bb * 3 + 2];
           }
-      } else {
-        // diagonal block keeps its upper triangle only; two records of the same camera add B + B^T
-        const double f = (ri == rj) ? 1.0 : 2.0;
-        double Yj[18];
-        if (ri != rj) {
-          const double* wi = &s_W[ri * kWStride];
 #pragma unroll
-          for (int a = 0; a < 6; ++a) sym3_mul(Vi, Wj[a * 3], Wj[a * 3 + 1], Wj[a * 3 + 2], &Yj[a * 3]);
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b) {
-              const double v1 = Y[a * 3] * Wj[b * 3] + Y[a * 3 + 1] * Wj[b * 3 + 1] + Y[a * 3 + 2] * Wj[b * 3 + 2];
-              const double v2 = Yj[a * 3] * wi[b * 3] + Yj[a * 3 + 1] * wi[b * 3 + 1] + Yj[a * 3 + 2] * wi[b * 3 + 2];
-              atomicAdd(&dst[a * 6 + b], -(v1 + v2));
-            }
-        } else {
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b) {
-              const double v = Y[a * 3] * Wj[b * 3] + Y[a * 3 + 1] * Wj[b * 3 + 1] + Y[a * 3 + 2] * Wj[b * 3 + 2];
-              atomicAdd(&dst[a * 6 + b], -v);
-            }
+          for (int bb = 0; bb < 6; ++bb) s_stage[grp * 36 + row * 6 + bb] = acc[bb];
         }
-        (void)f;
+        __syncthreads();
+        const int nround = min(kGroups, nblk - b0);
+        if (!(A.dbg & 4)) {
+          for (int idx = tid; idx < nround * 36; idx += kThreads) {
+            const int g = idx / 36, el = idx - g * 36;
+            const uint32_t desc = A.blk_desc[H.blk0 + b0 + g];
+            // work items of one block sit next to each other: the first of a run flushes the run's sum,
+            // so one wave-instruction never adds twice to the same address
+            if (g > 0 && A.blk_desc[H.blk0 + b0 + g - 1] == desc) continue;
+            double v = s_stage[idx];
+            for (int g2 = g + 1; g2 < nround && A.blk_desc[H.blk0 + b0 + g2] == desc; ++g2) v += s_stage[g2 * 36 + el];
+            const int li = desc & 0xff, lj = (desc >> 8) & 0xff;
+            const int ra = el / 6, cb = el - ra * 6;
+            if (v != 0.0 && (li != lj || cb >= ra))  // diagonal blocks keep their upper triangle only
+              atomicAdd(&A.Sblk[ut_block(s_slot[li], s_slot[lj], A.ncv) * 36 + el], -v);
+          }
+        }
+        __syncthreads();
       }
     }
   }
   __syncthreads();
 
-  // ---- P4: flush the LDS tile and per-camera vectors, chunk partials --------------------------
+  // ---- P4: flush the per-camera LDS accumulators, chunk partials ------------------------------
   if (MODE == MODE_FULL) {
-    for (int idx = tid; idx < kTileBlocks * 36; idx += kThreads) {
-      const double v = s_tile[idx];
-      if (v != 0.0 && !(A.dbg & 4)) {
-        const int blk = idx / 36, el = idx - blk * 36;
-        const int li = c_tile_li[blk], lj = c_tile_lj[blk];
-        atomicAdd(&A.Sblk[ut_block(s_slot[li], s_slot[lj], A.ncv) * 36 + el], v);
+    for (int idx = tid; idx < kTileCams * 21; idx += kThreads) {
+      const int lc = idx / 21;
+      const double v = s_U[idx];
+      if (lc < ncam && v != 0.0) {
+        int u = idx - lc * 21, i = 0;
+        while (u >= 6 - i) { u -= 6 - i; ++i; }  // packed (i, j >= i) -> i, j = i + u
+        atomicAdd(&A.Sblk[ut_block(s_slot[lc], s_slot[lc], A.ncv) * 36 + i * 6 + i + u], v);
       }
     }
   }
@@ -685,14 +668,7 @@ __global__ __launch_bounds__(kThreads) void k_pts_sqnorm(int64_t np, const uint1
 }
 
 // ---- launch wrappers ------------------------------------------------------------------------------
-void init_tile_tables(hipStream_t) {
-  uint8_t li[kTileBlocks], lj[kTileBlocks];
-  int b = 0;
-  for (int i = 0; i < kTileCams; ++i)
-    for (int j = i; j < kTileCams; ++j) { li[b] = (uint8_t)i; lj[b] = (uint8_t)j; ++b; }
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_tile_li), li, sizeof(li));
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_tile_lj), lj, sizeof(lj));
-}
+void init_tile_tables(hipStream_t) {}
 
 void launch_track_sweep(const SweepArgs& a, int nchunks, bool diag_only, hipStream_t s) {
   if (nchunks <= 0) return;

@@ -84,7 +84,8 @@ struct mpsfm_ba_handle {
   int32_t *d_intr_idx = nullptr, *d_cam_slot = nullptr;
   double *d_ps = nullptr, *d_diagV = nullptr;
   ChunkHdr* d_chunks = nullptr;
-  int32_t *d_chunk_cams = nullptr, *d_rec_cam = nullptr, *d_rec_pt = nullptr, *d_pt_rec_start = nullptr, *d_pt_pair_start = nullptr;
+  int32_t *d_chunk_cams = nullptr, *d_rec_cam = nullptr, *d_rec_pt = nullptr, *d_pt_rec_start = nullptr, *d_blk_ent_start = nullptr;
+  uint32_t *d_blk_desc = nullptr, *d_ents = nullptr;
   uint32_t* d_rec_meta = nullptr;
   uint16_t* d_pt_kv = nullptr;
   double *d_rec_xy = nullptr, *d_rec_d = nullptr, *d_rec_m = nullptr, *d_rec_a = nullptr;
@@ -111,7 +112,7 @@ static void free_handle(mpsfm_ba_handle* h) {
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->d_q, h->d_t, h->d_q2, h->d_t2, h->d_q0, h->d_t0, h->d_pts, h->d_pts2, h->d_pts0, h->d_intr, h->d_cmask,
                   h->d_cs, h->d_camtab, h->d_camtab2, h->d_intr_idx, h->d_cam_slot, h->d_ps, h->d_diagV, h->d_chunks,
-                  h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_pt_pair_start, h->d_rec_meta, h->d_pt_kv,
+                  h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -274,7 +275,12 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   // -- chunking
   std::vector<ChunkHdr> chunks;
   std::vector<int32_t> chunk_cams;
-  std::vector<int32_t> rec_cam, rec_pt, pt_rec_start((size_t)h->np + 1, 0), pt_pair_start((size_t)h->np + 1, 0);
+  std::vector<int32_t> rec_cam, rec_pt, pt_rec_start((size_t)h->np + 1, 0);
+  std::vector<uint32_t> blk_desc, ents;          // Schur pairs grouped by destination block, per chunk
+  std::vector<int32_t> blk_ent_start;
+  struct PairEnt { uint16_t key; uint32_t ent; };
+  std::vector<PairEnt> pe;
+  std::vector<std::pair<int, int>> blk_order;    // (count, first index into pe) per block of the open chunk
   std::vector<uint32_t> rec_meta;
   std::vector<uint16_t> pt_kv((size_t)h->np + 1, 0xffff);
   std::vector<double> rec_xy, rec_d, rec_m, rec_a;
@@ -290,11 +296,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       ChunkHdr H{};
       H.rec0 = (int32_t)rec_cam.size(); H.pt0 = (int32_t)c_first; H.npt = (int32_t)(end_pt - c_first);
       H.cam0 = (int32_t)chunk_cams.size(); H.ncam = (int32_t)cur_cams.size();
-      int pairs = 0;
+      pe.clear();
       for (int64_t k = c_first; k < end_pt; ++k) {
         const int p = order[k];
         pt_rec_start[k] = (int32_t)rec_cam.size();
-        pt_pair_start[k] = pairs;
+        const int rbase = (int)rec_cam.size() - H.rec0;  // chunk-relative index of this landmark's first record
         int kv = 0;
         for (int64_t r = prec[p]; r < prec[p + 1]; ++r) {
           const Rec& R = recs[r];
@@ -308,10 +314,49 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
           rec_xy.push_back(R.u); rec_xy.push_back(R.v); rec_d.push_back(R.d); rec_m.push_back(R.m); rec_a.push_back(R.a);
           nblk_reduced += ((R.flags & kRecHasReproj) ? 1 : 0) + ((R.flags & kRecHasDepth) ? 1 : 0);
         }
-        if (!P->pt_const[p]) { pt_kv[k] = (uint16_t)kv; pairs += kv * (kv + 1) / 2; nvarpts += 1; }
+        if (!P->pt_const[p]) {
+          pt_kv[k] = (uint16_t)kv;
+          nvarpts += 1;
+          // Schur pairs of this landmark: records rbase .. rbase+kv-1 have variable cameras (slot-sorted)
+          const uint32_t lpt = (uint32_t)(k - c_first);
+          for (int i = 0; i < kv; ++i) {
+            const uint32_t li = rec_meta[H.rec0 + rbase + i] & 0xff;
+            for (int j = i; j < kv; ++j) {
+              const uint32_t lj = rec_meta[H.rec0 + rbase + j] & 0xff;
+              pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + i) | ((uint32_t)(rbase + j) << 8) | (lpt << 16)});
+              // two records of one camera: the diagonal block needs B + B^T
+              if (li == lj && i != j)
+                pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + j) | ((uint32_t)(rbase + i) << 8) | (lpt << 16)});
+            }
+          }
+        }
       }
       H.nrec = (int32_t)rec_cam.size() - H.rec0;
-      H.npairs = pairs;
+      // group the pairs by destination block; heaviest blocks first (they are dealt round-robin to lane groups)
+      std::stable_sort(pe.begin(), pe.end(), [](const PairEnt& a, const PairEnt& b) { return a.key < b.key; });
+      blk_order.clear();
+      for (size_t i = 0; i < pe.size();) {
+        size_t j = i;
+        while (j < pe.size() && pe[j].key == pe[i].key) ++j;
+        blk_order.emplace_back((int)(j - i), (int)i);
+        i = j;
+      }
+      std::stable_sort(blk_order.begin(), blk_order.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+      // work items: runs of at most kItemPairs pairs of one block; heaviest first
+      H.blk0 = (int32_t)blk_desc.size();
+      H.ent0 = (int32_t)ents.size();
+      H.nent = (int32_t)pe.size();
+      std::vector<std::pair<int, int>> items;  // (count, first index into pe)
+      for (const auto& bo : blk_order)
+        for (int t = 0; t < bo.first; t += kItemPairs) items.emplace_back(std::min(kItemPairs, bo.first - t), bo.second + t);
+      std::stable_sort(items.begin(), items.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+      H.nblk = (int32_t)items.size();
+      for (const auto& it : items) {
+        blk_desc.push_back(pe[it.second].key);
+        blk_ent_start.push_back((int32_t)(ents.size() - (size_t)H.ent0));
+        for (int t = 0; t < it.first; ++t) ents.push_back(pe[it.second + t].ent);
+      }
+      blk_ent_start.push_back((int32_t)(ents.size() - (size_t)H.ent0));  // per-chunk sentinel
       chunk_cams.insert(chunk_cams.end(), cur_cams.begin(), cur_cams.end());
       chunks.push_back(H);
       cur_cams.clear(); c_first = end_pt; c_nrec = 0;
@@ -328,8 +373,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       uni.clear();
       std::set_union(cur_cams.begin(), cur_cams.end(), pc.begin(), pc.end(), std::back_inserter(uni));
       const bool too_big = (c_nrec + r_p > kObsMax) || (k - c_first + 1 > kPtsMax) || ((int)uni.size() > kLocalCamsMax);
-      const bool spills = ((int)uni.size() > kTileCams) && (c_nrec >= kObsMax / 2) && ((int)cur_cams.size() <= kTileCams);
-      if (k > c_first && (too_big || spills)) {
+      if (k > c_first && too_big) {
         close_chunk(k);
         uni = pc;
       }
@@ -338,6 +382,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     }
     close_chunk(h->np_chunked);
   }
+  if (ents.size() > (size_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "too many Schur pairs for 32-bit entry offsets");
   h->nchunks = (int)chunks.size();
   h->nrec = (int64_t)rec_cam.size();
   h->nblocks_reduced = nblk_reduced;
@@ -374,7 +419,9 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_rec_m, rec_m))) return rc;
   if ((rc = dev_upload(&h->d_rec_a, rec_a))) return rc;
   if ((rc = dev_upload(&h->d_pt_rec_start, pt_rec_start))) return rc;
-  if ((rc = dev_upload(&h->d_pt_pair_start, pt_pair_start))) return rc;
+  if ((rc = dev_upload(&h->d_blk_desc, blk_desc))) return rc;
+  if ((rc = dev_upload(&h->d_blk_ent_start, blk_ent_start))) return rc;
+  if ((rc = dev_upload(&h->d_ents, ents))) return rc;
   if ((rc = dev_upload(&h->d_pt_kv, pt_kv))) return rc;
   if ((rc = dev_upload(&h->d_fx_cam, fx_cam))) return rc;
   if ((rc = dev_upload(&h->d_fx_pt, fx_pt))) return rc;
@@ -439,7 +486,7 @@ static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius) {
   SweepArgs a{};
   a.chunks = h->d_chunks; a.chunk_cams = h->d_chunk_cams; a.rec_cam = h->d_rec_cam; a.rec_meta = h->d_rec_meta;
   a.rec_xy = h->d_rec_xy; a.rec_d = h->d_rec_d; a.rec_m = h->d_rec_m; a.rec_a = h->d_rec_a;
-  a.pt_rec_start = h->d_pt_rec_start; a.pt_kv = h->d_pt_kv; a.pt_pair_start = h->d_pt_pair_start;
+  a.pt_rec_start = h->d_pt_rec_start; a.pt_kv = h->d_pt_kv; a.blk_desc = h->d_blk_desc; a.blk_ent_start = h->d_blk_ent_start; a.ents = h->d_ents;
   a.camtab = h->d_camtab; a.pts = h->d_pts; a.ps = h->d_ps; a.loss = h->loss;
   a.radius = radius; a.min_diag = h->opt.min_lm_diagonal; a.max_diag = h->opt.max_lm_diagonal; a.ncv = h->ncv; a.dbg = (g_dbg_flags >> 8) & 0xff;
   a.Sblk = h->d_Sblk; a.gc = h->d_gc; a.wv = h->d_wv; a.diagU = h->d_diagU; a.part = h->d_part; a.diagV = h->d_diagV;

@@ -9,14 +9,30 @@
 
 namespace mpsfm {
 
+// tuning knobs (overridable with -D for experiments; scripts/sweep_variants.sh)
+#ifndef MPSFM_TILE_CAMS
+#define MPSFM_TILE_CAMS 16
+#endif
+#ifndef MPSFM_ITEM_PAIRS
+#define MPSFM_ITEM_PAIRS 1000000
+#endif
+#ifndef MPSFM_ENT_STAGE
+#define MPSFM_ENT_STAGE 1024
+#endif
+#ifndef MPSFM_OBS_MAX
+#define MPSFM_OBS_MAX 192
+#endif
+
 // ---- track-sweep chunk geometry ----------------------------------------------------------
 // A chunk = a group of consecutive (re-ordered) landmarks processed by one workgroup.
 constexpr int kThreads = 256;   // workgroup size of the sweep kernels
-constexpr int kObsMax = 192;    // merged (camera, landmark) records per chunk
-constexpr int kPtsMax = 96;     // landmarks per chunk
-constexpr int kTileCams = 16;   // local cameras whose S blocks are accumulated in LDS
-constexpr int kTileBlocks = kTileCams * (kTileCams + 1) / 2;  // upper block triangle
+constexpr int kObsMax = MPSFM_OBS_MAX;    // merged (camera, landmark) records per chunk
+constexpr int kPtsMax = MPSFM_OBS_MAX / 2;     // landmarks per chunk
+constexpr int kTileCams = MPSFM_TILE_CAMS;   // local cameras whose U blocks / g_c are accumulated in LDS
 constexpr int kLocalCamsMax = 64;  // local camera list length (beyond kTileCams: direct atomics)
+constexpr int kPairGroup = 6;   // lanes cooperating on one 6x6 block of the reduced system (one row each)
+constexpr int kItemPairs = MPSFM_ITEM_PAIRS;  // pairs per Schur work item (heavier blocks are split for balance)
+constexpr int kEntStage = MPSFM_ENT_STAGE; // pair entries of a chunk staged in LDS (larger chunks read them from HBM)
 constexpr int kWStride = 19;    // padded row stride (doubles) of the per-record W block in LDS
 constexpr int kCamRec = 24;     // doubles per camera table record
 
@@ -27,8 +43,8 @@ struct ChunkHdr {
   int32_t rec0, nrec;    // merged records [rec0, rec0+nrec)
   int32_t pt0, npt;      // re-ordered landmarks [pt0, pt0+npt)
   int32_t cam0, ncam;    // local camera list in chunk_cams[cam0 ..)
-  int32_t npairs;        // sum over variable landmarks of kv(kv+1)/2
-  int32_t pad;
+  int32_t blk0, nblk;    // Schur work items (a destination block of S + a run of its pairs) of this chunk
+  int32_t ent0, nent;    // the chunk's pair entries
 };
 
 // record meta word: lcam | lpt << 8 | flags << 16
@@ -147,7 +163,9 @@ struct SweepArgs {
   const double* rec_a;           // depth loss scale
   const int32_t* pt_rec_start;   // [np+1]
   const uint16_t* pt_kv;         // [np] records with a variable camera (0: constant landmark)
-  const int32_t* pt_pair_start;  // [np] exclusive prefix of kv(kv+1)/2 inside the chunk
+  const uint32_t* blk_desc;      // per destination block: li | lj << 8
+  const int32_t* blk_ent_start;  // [nblocks+1] entry range of each block
+  const uint32_t* ents;          // per Schur pair: ri | rj << 8 | lpt << 16 (chunk-relative records)
   const double* camtab;          // [nc][24] at the linearisation point
   const double* pts;             // [np][3]
   const double* ps;              // [np][3] Jacobi scale (0: constant landmark)

@@ -104,7 +104,7 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   double y = __builtin_amdgcn_rsq(d);
   const double hd = 0.5 * d;
   y = y * __builtin_fma(-hd * y, y, 1.5);
-  y = y * __builtin_fma(-hd * y, y, 1.5);
+  y = y * __builtin_fma(-hd * y, y, 1.5);  // second step kept: v_rsq_f64 alone is good to ~2^-26
   return y;
 }
 
@@ -180,48 +180,94 @@ __device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt,
 // j+1 are turned into L right away: each of those waves re-derives the updated diagonal tile,
 // factors it in registers and solves its own tile against it.  The wave that owns the diagonal
 // tile also stores L^-T of it (LinvT) for the back substitution.
+// half-tile variants (rows 16 mi .. 16 mi + 15) for the two waves of a trailing-update workgroup
+__device__ __forceinline__ void half_load_acc(const double* __restrict__ T, int lane, int mi, v4d acc[2]) {
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[ni][r] = T[(16 * mi + (lane >> 4) + 4 * r) * kTile + 16 * ni + (lane & 15)];
+}
+__device__ __forceinline__ void half_store_acc(double* __restrict__ T, int lane, int mi, const v4d acc[2]) {
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[(16 * mi + (lane >> 4) + 4 * r) * kTile + 16 * ni + (lane & 15)] = acc[ni][r];
+}
+__device__ __forceinline__ void half_syrk_sub(const double* __restrict__ At, const double* __restrict__ Bt, int lane, int mi,
+                                              v4d acc[2]) {
+  const int row = lane & 15, kg = lane >> 4;
+  double a[8], b[2][8];
+  {
+    const double2* pa = reinterpret_cast<const double2*>(At + (16 * mi + row) * kTile + 8 * kg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { const double2 x = pa[s]; a[2 * s] = -x.x; a[2 * s + 1] = -x.y; }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const double2* pb = reinterpret_cast<const double2*>(Bt + (16 * h + row) * kTile + 8 * kg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { const double2 y = pb[s]; b[h][2 * s] = y.x; b[h][2 * s + 1] = y.y; }
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[ni][s], acc[ni], 0, 0, 0);
+}
+
 int g_dbg_flags = 0;
 extern "C" void mpsfm_debug_set(int f) { g_dbg_flags = f; }
-__global__ __launch_bounds__(64) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg) {
+
+// One step of the right-looking factorisation, two waves per tile.  j = -1: factor tile column 0 only.
+//   trailing tile (tk > j+1):  A[ti][tk] -= L[ti][j] L[tk][j]^T, one 16-row half per wave.
+//   panel tile (tk == j+1):    wave 0 re-derives the updated diagonal tile and factors it in registers,
+//                              wave 1 updates the workgroup's own tile meanwhile and then solves it
+//                              against the factor (X L^-T); the workgroup that owns the diagonal tile
+//                              stores L and L^-T (kept for the back substitution).
+__global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg) {
   __shared__ double s_T[kTile][kTile + 1];
   __shared__ double s_X[kTile][kTile + 1];
   __shared__ double s_Lt[kTile * kTile];
   __shared__ double s_inv[kTile];
   __shared__ double s_col[2][kTile];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tk = j + 1 + blockIdx.y;
   const int ti = j + 1 + blockIdx.x;
   if (ti < tk || tk >= nt || ti > nt) return;
   double* C = A + lt_tile(ti, tk) * kTileElems;
-  v4d acc[2][2];
-  tile_load_acc(C, lane, acc);
-  if (j >= 0 && !(dbg & 4)) tile_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, acc);
   if (tk != j + 1) {
-    tile_store_acc(C, kTile, lane, acc);
+    v4d acc[2];
+    half_load_acc(C, lane, wave, acc);
+    if (!(dbg & 4)) half_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, wave, acc);
+    half_store_acc(C, lane, wave, acc);
     return;
   }
   // ---- panel column j+1 -------------------------------------------------------------------
   const int row = lane & 31;
   const bool diag = (ti == tk);
-  if (diag) {
-    tile_store_acc(&s_T[0][0], kTile + 1, lane, acc);
-  } else {
+  if (wave == 0) {
+    // updated diagonal tile -> s_T
     v4d dacc[2][2];
-    tile_load_acc(A + lt_tile(tk, tk) * kTileElems, lane, dacc);
-    if (j >= 0) {
+    const double* Dg = A + lt_tile(tk, tk) * kTileElems;
+    tile_load_acc(Dg, lane, dacc);
+    if (j >= 0 && !(dbg & 4)) {
       const double* Lk = A + lt_tile(tk, j) * kTileElems;
-      if (!(dbg & 4)) tile_syrk_sub(Lk, Lk, lane, dacc);
+      tile_syrk_sub(Lk, Lk, lane, dacc);
     }
     tile_store_acc(&s_T[0][0], kTile + 1, lane, dacc);
+  } else if (!diag) {
+    // this workgroup's own updated tile -> s_X
+    v4d acc[2][2];
+    tile_load_acc(C, lane, acc);
+    if (j >= 0 && !(dbg & 4)) tile_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, acc);
     tile_store_acc(&s_X[0][0], kTile + 1, lane, acc);
   }
   __syncthreads();
-  bool ok = true;
-  {
-    // factor the diagonal tile, one row per lane; only L^T and 1/diag survive (in LDS)
+  double x[kTile];
+  if (wave == 0) {
     double a[kTile];
 #pragma unroll
     for (int c = 0; c < kTile; ++c) a[c] = s_T[row][c];
+    bool ok = true;
     if (!(dbg & 1)) ok = potrf_rows(a, lane, s_inv, s_col);
     if (lane < kTile) {
 #pragma unroll
@@ -232,11 +278,8 @@ __global__ __launch_bounds__(64) void k_chol_step(double* A, double* LinvT, int 
 #pragma unroll
       for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(c <= lane ? a[c] : 0.0, c + 1 <= lane ? a[c + 1] : 0.0);
     }
-  }
-  __syncthreads();
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    double x[kTile];
+    if (diag && !ok && lane == 0) atomicExch(fail, 1);
+  } else {
     if (diag) {
 #pragma unroll
       for (int c = 0; c < kTile; ++c) x[c] = (c == row) ? 1.0 : 0.0;  // identity: x L^-T = row of L^-T
@@ -244,6 +287,9 @@ __global__ __launch_bounds__(64) void k_chol_step(double* A, double* LinvT, int 
 #pragma unroll
       for (int c = 0; c < kTile; ++c) x[c] = s_X[row][c];
     }
+  }
+  __syncthreads();
+  if (wave == 1) {
     if (!(dbg & 2)) trsm_row(x, s_Lt, s_inv);
     if (lane < kTile) {
       double2* dst = diag ? reinterpret_cast<double2*>(LinvT + (size_t)tk * kTileElems + lane * kTile)
@@ -252,7 +298,6 @@ __global__ __launch_bounds__(64) void k_chol_step(double* A, double* LinvT, int 
       for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(x[c], x[c + 1]);
     }
   }
-  if (diag && !ok && lane == 0) atomicExch(fail, 1);
 }
 
 // ---- back substitution  y = L^-T z  in groups of kBsG tile rows --------------------------------
@@ -369,7 +414,7 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   for (int j = -1; j <= nt - 2; ++j) {
     const int rows = nt - j;      // ti in [j+1, nt]
     const int cols = (j < 0) ? 1 : nt - 1 - j;  // tk in [j+1, nt-1]; the first step only factors column 0
-    hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(64), 0, s, A, LinvT, nt, j, fail, g_dbg_flags);
+    hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(128), 0, s, A, LinvT, nt, j, fail, g_dbg_flags);
   }
   hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
   for (int t1 = nt; t1 > 0; t1 -= kBsG) {
