@@ -1,0 +1,13 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for profiles/: kernel-trace stats and (in separate passes) the
+# FETCH_SIZE / WRITE_SIZE counters of the bench command.  Run on the GPU box from the repo root.
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $CMD > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- $CMD > "$OUT/bench_write.json" 2> "$OUT/write.err"
+python3 scripts/summarize_profile.py "$OUT" "$TAG"
