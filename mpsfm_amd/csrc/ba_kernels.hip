@@ -520,6 +520,260 @@ __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
   }
 }
 
+// decode q in [0, k(k+1)/2) -> (i, j), i <= j < k, row-major upper triangle
+__device__ __forceinline__ void tri_decode(int64_t q, int k, int& i, int& j) {
+  const double b = 2.0 * k + 1.0;
+  int64_t ii = (int64_t)((b - sqrt(b * b - 8.0 * (double)q)) * 0.5);
+  if (ii < 0) ii = 0;
+  if (ii > k - 1) ii = k - 1;
+  while (ii > 0 && ii * k - (ii * (ii - 1)) / 2 > q) --ii;       // row start(i) = i*k - i(i-1)/2
+  while ((ii + 1) * k - ((ii + 1) * ii) / 2 <= q) ++ii;
+  i = (int)ii;
+  j = (int)(q - (ii * k - (ii * (ii - 1)) / 2) + ii);
+}
+
+// block-wide sum of N doubles per thread; result valid in every thread
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double* s_buf /* N * 4 */) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double w = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) s_buf[k * 4 + (threadIdx.x >> 6)] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = (s_buf[k * 4] + s_buf[k * 4 + 1]) + (s_buf[k * 4 + 2] + s_buf[k * 4 + 3]);
+  __syncthreads();
+}
+
+// Track sweep of ONE landmark whose track is too long for a chunk: the workgroup strides over the
+// records; W goes to an HBM scratch; U / g_c / Schur blocks are added to the reduced system directly.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_long_track_sweep(SweepArgs A) {
+  __shared__ double s_buf[9 * 4];
+  __shared__ double s_vi[9];
+  const int tid = threadIdx.x;
+  const LongHdr H = A.lhdr[blockIdx.x];
+  const int pix = H.pt;
+  const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
+  const double psc[3] = {A.ps[3 * pix], A.ps[3 * pix + 1], A.ps[3 * pix + 2]};
+  const bool pvar = A.pt_kv[pix] != 0xffff;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // V (6), g (3)
+  double my_cost = 0.0, my_bad = 0.0;
+  for (int r = tid; r < H.nrec; r += kThreads) {
+    const int rix = H.rec0 + r;
+    const uint32_t meta = A.rec_meta[rix];
+    const int cam = A.rec_cam[rix];
+    const int slot = A.cam_slot[cam];
+    const double2 xy = reinterpret_cast<const double2*>(A.rec_xy)[rix];
+    double d = 1.0, m = 0.0, a = 1.0;
+    if (meta & kRecHasDepth) { d = A.rec_d[rix]; m = A.rec_m[rix]; a = A.rec_a[rix]; }
+    RecLin L;
+    linearize_record(A.camtab + (size_t)cam * kCamRec, X, psc, meta, xy.x, xy.y, d, m, a, A.loss, L);
+    my_cost += L.cost;
+    if (!L.ok) { my_bad += 1.0; continue; }
+    if (psc[0] != 0.0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double j0 = L.Jp[3 * q], j1 = L.Jp[3 * q + 1], j2 = L.Jp[3 * q + 2];
+        acc[0] += j0 * j0; acc[1] += j0 * j1; acc[2] += j0 * j2; acc[3] += j1 * j1; acc[4] += j1 * j2; acc[5] += j2 * j2;
+        acc[6] += j0 * L.r[q]; acc[7] += j1 * L.r[q]; acc[8] += j2 * L.r[q];
+      }
+    }
+    if (slot >= 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        atomicAdd(&A.diagU[(size_t)slot * 6 + i], L.Jc[i] * L.Jc[i] + L.Jc[6 + i] * L.Jc[6 + i] + L.Jc[12 + i] * L.Jc[12 + i]);
+      if (MODE == MODE_FULL) {
+        double* gS = &A.Sblk[ut_block(slot, slot, A.ncv) * 36];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          atomicAdd(&A.gc[(size_t)slot * 6 + i], L.Jc[i] * L.r[0] + L.Jc[6 + i] * L.r[1] + L.Jc[12 + i] * L.r[2]);
+#pragma unroll
+          for (int j = i; j < 6; ++j)
+            atomicAdd(&gS[i * 6 + j], L.Jc[i] * L.Jc[j] + L.Jc[6 + i] * L.Jc[6 + j] + L.Jc[12 + i] * L.Jc[12 + j]);
+        }
+        double* w = A.wl + (size_t)(H.w0 + r) * 18;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) w[i * 3 + j] = L.Jc[i] * L.Jp[j] + L.Jc[6 + i] * L.Jp[3 + j] + L.Jc[12 + i] * L.Jp[6 + j];
+      }
+    }
+  }
+  block_sum<9>(acc, s_buf);
+  if (MODE == MODE_DIAG) {
+    if (tid == 0) { A.diagV[3 * pix] = acc[0]; A.diagV[3 * pix + 1] = acc[3]; A.diagV[3 * pix + 2] = acc[5]; }
+    return;
+  }
+  double my_gmax = 0.0;
+  if (tid == 0) {
+    double Vi[6] = {0, 0, 0, 0, 0, 0}, vg[3] = {0, 0, 0};
+    if (pvar) {
+      double V[6] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]};
+      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
+      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
+      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
+      if (!spd3_inverse(V, Vi)) { my_bad += 1.0; for (int k = 0; k < 6; ++k) Vi[k] = 0.0; }
+      sym3_mul(Vi, acc[6], acc[7], acc[8], vg);
+      my_gmax = fmax(fabs(acc[6] / psc[0]), fmax(fabs(acc[7] / psc[1]), fabs(acc[8] / psc[2])));
+    }
+    for (int k = 0; k < 6; ++k) s_vi[k] = Vi[k];
+    for (int k = 0; k < 3; ++k) s_vi[6 + k] = vg[k];
+  }
+  __syncthreads();
+  if (pvar) {
+    double Vi[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Vi[k] = s_vi[k];
+    const double v0 = s_vi[6], v1 = s_vi[7], v2 = s_vi[8];
+    __threadfence();  // the W rows written above are read back by other threads of this workgroup
+    __syncthreads();
+    for (int r = tid; r < H.kv; r += kThreads) {
+      const double* w = A.wl + (size_t)(H.w0 + r) * 18;
+      const int slot = A.cam_slot[A.rec_cam[H.rec0 + r]];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) atomicAdd(&A.wv[(size_t)slot * 6 + i], w[i * 3] * v0 + w[i * 3 + 1] * v1 + w[i * 3 + 2] * v2);
+    }
+    const int64_t npairs = (int64_t)H.kv * (H.kv + 1) / 2;
+    for (int64_t e = tid; e < npairs; e += kThreads) {
+      int i, j;
+      tri_decode(e, H.kv, i, j);
+      const int si = A.cam_slot[A.rec_cam[H.rec0 + i]], sj = A.cam_slot[A.rec_cam[H.rec0 + j]];
+      const double* wi = A.wl + (size_t)(H.w0 + i) * 18;
+      const double* wj = A.wl + (size_t)(H.w0 + j) * 18;
+      double Y[18], Wj[18];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) sym3_mul(Vi, wi[a * 3], wi[a * 3 + 1], wi[a * 3 + 2], &Y[a * 3]);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) Wj[k] = wj[k];
+      double* dst = &A.Sblk[ut_block(si, sj, A.ncv) * 36];
+      if (si != sj) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b)
+            atomicAdd(&dst[a * 6 + b], -(Y[a * 3] * Wj[b * 3] + Y[a * 3 + 1] * Wj[b * 3 + 1] + Y[a * 3 + 2] * Wj[b * 3 + 2]));
+      } else {
+        double Yj[18];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) sym3_mul(Vi, Wj[a * 3], Wj[a * 3 + 1], Wj[a * 3 + 2], &Yj[a * 3]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = a; b < 6; ++b) {
+            double v = Y[a * 3] * Wj[b * 3] + Y[a * 3 + 1] * Wj[b * 3 + 1] + Y[a * 3 + 2] * Wj[b * 3 + 2];
+            if (i != j) v += Yj[a * 3] * wi[b * 3] + Yj[a * 3 + 1] * wi[b * 3 + 1] + Yj[a * 3 + 2] * wi[b * 3 + 2];
+            atomicAdd(&dst[a * 6 + b], -v);
+          }
+      }
+    }
+  }
+  double red[3] = {my_cost, my_bad, 0.0};
+  block_sum<3>(red, s_buf);
+  const double g = wave_max(my_gmax);  // only thread 0 (wave 0) holds a value
+  if (tid == 0) {
+    double* p = A.part + (size_t)(A.nchunks + blockIdx.x) * 4;
+    p[0] = red[0]; p[1] = red[1]; p[2] = g; p[3] = 0.0;
+  }
+}
+
+// Update sweep of one long-track landmark (see k_update_sweep).
+__global__ __launch_bounds__(kThreads) void k_long_update_sweep(SweepArgs A) {
+  __shared__ double s_buf[9 * 4];
+  __shared__ double s_b[6];
+  const int tid = threadIdx.x;
+  const LongHdr H = A.lhdr[blockIdx.x];
+  const int pix = H.pt;
+  const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
+  const double psc[3] = {A.ps[3 * pix], A.ps[3 * pix + 1], A.ps[3 * pix + 2]};
+  const bool pvar = A.pt_kv[pix] != 0xffff;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double bad = 0.0;
+  for (int r = tid; r < H.nrec; r += kThreads) {
+    const int rix = H.rec0 + r;
+    const uint32_t meta = A.rec_meta[rix];
+    const int cam = A.rec_cam[rix];
+    const int slot = A.cam_slot[cam];
+    const double2 xy = reinterpret_cast<const double2*>(A.rec_xy)[rix];
+    double d = 1.0, m = 0.0, a = 1.0;
+    if (meta & kRecHasDepth) { d = A.rec_d[rix]; m = A.rec_m[rix]; a = A.rec_a[rix]; }
+    RecLin L;
+    linearize_record(A.camtab + (size_t)cam * kCamRec, X, psc, meta, xy.x, xy.y, d, m, a, A.loss, L);
+    if (!L.ok) { bad += 1.0; continue; }
+    double mrow[3] = {0, 0, 0};
+    if (slot >= 0) {
+      const double* y = A.yc + (size_t)slot * 6;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        mrow[q] = L.Jc[6 * q] * y[0] + L.Jc[6 * q + 1] * y[1] + L.Jc[6 * q + 2] * y[2] + L.Jc[6 * q + 3] * y[3] +
+                  L.Jc[6 * q + 4] * y[4] + L.Jc[6 * q + 5] * y[5];
+    }
+    if (psc[0] != 0.0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double j0 = L.Jp[3 * q], j1 = L.Jp[3 * q + 1], j2 = L.Jp[3 * q + 2];
+        acc[0] += j0 * j0; acc[1] += j0 * j1; acc[2] += j0 * j2; acc[3] += j1 * j1; acc[4] += j1 * j2; acc[5] += j2 * j2;
+        const double rr = L.r[q] + mrow[q];
+        acc[6] += j0 * rr; acc[7] += j1 * rr; acc[8] += j2 * rr;
+      }
+    }
+  }
+  block_sum<9>(acc, s_buf);
+  double step_sq = 0.0, xn_sq = 0.0;
+  if (tid == 0) {
+    double yp[3] = {0, 0, 0}, X2[3] = {X[0], X[1], X[2]};
+    if (pvar) {
+      double V[6] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]}, Vi[6];
+      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
+      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
+      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
+      if (!spd3_inverse(V, Vi)) {
+        bad += 1.0;
+      } else {
+        sym3_mul(Vi, -acc[6], -acc[7], -acc[8], yp);
+        for (int k = 0; k < 3; ++k) {
+          const double dl = psc[k] * yp[k];
+          X2[k] = X[k] + dl; step_sq += dl * dl; xn_sq += X2[k] * X2[k];
+        }
+      }
+    }
+    for (int k = 0; k < 3; ++k) { s_b[k] = yp[k]; s_b[3 + k] = X2[k]; A.pts2[3 * pix + k] = X2[k]; }
+  }
+  __syncthreads();
+  const double y0 = s_b[0], y1 = s_b[1], y2 = s_b[2];
+  const double X2[3] = {s_b[3], s_b[4], s_b[5]};
+  double mcc = 0.0, cand = 0.0;
+  for (int r = tid; r < H.nrec; r += kThreads) {
+    const int rix = H.rec0 + r;
+    const uint32_t meta = A.rec_meta[rix];
+    const int cam = A.rec_cam[rix];
+    const int slot = A.cam_slot[cam];
+    const double2 xy = reinterpret_cast<const double2*>(A.rec_xy)[rix];
+    double d = 1.0, m = 0.0, a = 1.0;
+    if (meta & kRecHasDepth) { d = A.rec_d[rix]; m = A.rec_m[rix]; a = A.rec_a[rix]; }
+    RecLin L;
+    linearize_record(A.camtab + (size_t)cam * kCamRec, X, psc, meta, xy.x, xy.y, d, m, a, A.loss, L);
+    if (!L.ok) continue;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double mm = L.Jp[3 * q] * y0 + L.Jp[3 * q + 1] * y1 + L.Jp[3 * q + 2] * y2;
+      if (slot >= 0) {
+        const double* y = A.yc + (size_t)slot * 6;
+        mm += L.Jc[6 * q] * y[0] + L.Jc[6 * q + 1] * y[1] + L.Jc[6 * q + 2] * y[2] + L.Jc[6 * q + 3] * y[3] +
+              L.Jc[6 * q + 4] * y[4] + L.Jc[6 * q + 5] * y[5];
+      }
+      mcc -= mm * (L.r[q] + 0.5 * mm);
+    }
+    bool ok2 = true;
+    const double cc = record_cost(A.camtab2 + (size_t)cam * kCamRec, X2, meta, xy.x, xy.y, d, m, a, A.loss, ok2);
+    if (ok2) cand += cc; else bad += 1.0;
+  }
+  double red[5] = {cand, bad, mcc, step_sq, xn_sq};
+  block_sum<5>(red, s_buf);
+  if (tid < 5) A.part2[(size_t)(A.nchunks + blockIdx.x) * 8 + tid] = red[tid];
+}
+
 // cost of a record list at given cameras / landmarks (fixed blocks, eval_cost): per-block partials
 __global__ __launch_bounds__(kThreads) void k_cost_records(CostArgs A) {
   __shared__ double s_red[3 * (kThreads / 64)];
@@ -671,13 +925,18 @@ __global__ __launch_bounds__(kThreads) void k_pts_sqnorm(int64_t np, const uint1
 void init_tile_tables(hipStream_t) {}
 
 void launch_track_sweep(const SweepArgs& a, int nchunks, bool diag_only, hipStream_t s) {
-  if (nchunks <= 0) return;
-  if (diag_only) hipLaunchKernelGGL(k_track_sweep<MODE_DIAG>, dim3(nchunks), dim3(kThreads), 0, s, a);
-  else hipLaunchKernelGGL(k_track_sweep<MODE_FULL>, dim3(nchunks), dim3(kThreads), 0, s, a);
+  if (nchunks > 0) {
+    if (diag_only) hipLaunchKernelGGL(k_track_sweep<MODE_DIAG>, dim3(nchunks), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL(k_track_sweep<MODE_FULL>, dim3(nchunks), dim3(kThreads), 0, s, a);
+  }
+  if (a.nlong > 0) {
+    if (diag_only) hipLaunchKernelGGL(k_long_track_sweep<MODE_DIAG>, dim3(a.nlong), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL(k_long_track_sweep<MODE_FULL>, dim3(a.nlong), dim3(kThreads), 0, s, a);
+  }
 }
 void launch_update_sweep(const SweepArgs& a, int nchunks, hipStream_t s) {
-  if (nchunks <= 0) return;
-  hipLaunchKernelGGL(k_update_sweep, dim3(nchunks), dim3(kThreads), 0, s, a);
+  if (nchunks > 0) hipLaunchKernelGGL(k_update_sweep, dim3(nchunks), dim3(kThreads), 0, s, a);
+  if (a.nlong > 0) hipLaunchKernelGGL(k_long_update_sweep, dim3(a.nlong), dim3(kThreads), 0, s, a);
 }
 void launch_cost_records(const CostArgs& a, int nblocks, hipStream_t s) {
   hipLaunchKernelGGL(k_cost_records, dim3(nblocks), dim3(kThreads), 0, s, a);

@@ -73,7 +73,9 @@ struct mpsfm_ba_handle {
   int64_t np = 0, np_chunked = 0;   // re-ordered landmarks (all referenced) / those inside chunks
   int64_t nrec = 0, nfixed = 0, nblocks_total = 0, nblocks_reduced = 0;
   double nblocks_global = 0, nblocks_reduced_global = 0, nvarpts_global = 0;
-  int ncv = 0, n = 0, nt = 0, nchunks = 0;
+  int ncv = 0, n = 0, nt = 0, nchunks = 0, nlong = 0;
+  LongHdr* d_lhdr = nullptr;
+  double* d_wl = nullptr;
   int64_t red_count = 0, sblk_count = 0;
   std::vector<int32_t> perm;        // re-ordered landmark -> caller's index
   std::vector<int32_t> cam_slot_h;
@@ -114,7 +116,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_cs, h->d_camtab, h->d_camtab2, h->d_intr_idx, h->d_cam_slot, h->d_ps, h->d_diagV, h->d_chunks,
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
-                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail};
+                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -261,7 +263,18 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     if (na != nb) return na < nb;
     return a < b;
   });
-  h->np_chunked = (int64_t)order.size();
+  // landmarks whose track does not fit one chunk are swept by a workgroup of their own
+  auto is_long = [&](int p) {
+    const int64_t r_p = prec[p + 1] - prec[p];
+    if (r_p > kObsMax) return true;
+    int distinct = 0, last = -2;
+    for (int64_t r = prec[p]; r < prec[p + 1]; ++r)
+      if (recs[r].slot >= 0 && recs[r].slot != last) { ++distinct; last = recs[r].slot; }
+    return distinct > kLocalCamsMax;
+  };
+  auto first_long = std::stable_partition(order.begin(), order.end(), [&](int p) { return !is_long(p); });
+  h->np_chunked = (int64_t)(first_long - order.begin());
+  const int64_t n_long = (int64_t)(order.end() - first_long);
   {
     std::vector<uint8_t> seen((size_t)npu + 1, 0);
     for (int p : order) seen[p] = 1;
@@ -368,8 +381,6 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       pc.clear();
       for (int64_t r = prec[p]; r < prec[p + 1]; ++r) if (recs[r].slot >= 0) pc.push_back(recs[r].slot);
       pc.erase(std::unique(pc.begin(), pc.end()), pc.end());  // records are slot-sorted
-      if (r_p > kObsMax || (int)pc.size() > kLocalCamsMax)
-        return fail(MPSFM_EUNSUPPORTED, "a landmark track longer than " + std::to_string(kObsMax) + " records is not supported yet");
       uni.clear();
       std::set_union(cur_cams.begin(), cur_cams.end(), pc.begin(), pc.end(), std::back_inserter(uni));
       const bool too_big = (c_nrec + r_p > kObsMax) || (k - c_first + 1 > kPtsMax) || ((int)uni.size() > kLocalCamsMax);
@@ -386,8 +397,33 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   h->nchunks = (int)chunks.size();
   h->nrec = (int64_t)rec_cam.size();
   h->nblocks_reduced = nblk_reduced;
-  pt_rec_start[h->np_chunked] = (int32_t)h->nrec;
-  for (int64_t k = h->np_chunked + 1; k <= h->np; ++k) pt_rec_start[k] = (int32_t)h->nrec;
+  std::vector<LongHdr> lhdr;
+  int64_t wl_rows = 0;
+  for (int64_t k = h->np_chunked; k < h->np_chunked + n_long; ++k) {
+    const int p = order[k];
+    LongHdr L{};
+    L.rec0 = (int32_t)rec_cam.size(); L.pt = (int32_t)k; L.w0 = wl_rows;
+    pt_rec_start[k] = L.rec0;
+    int kv = 0;
+    for (int64_t r = prec[p]; r < prec[p + 1]; ++r) {
+      const Rec& R = recs[r];
+      if (R.slot >= 0) ++kv;
+      rec_cam.push_back(R.cam); rec_pt.push_back((int32_t)k);
+      rec_meta.push_back((R.slot >= 0 ? 0u : kLcamConst) | R.flags);
+      rec_xy.push_back(R.u); rec_xy.push_back(R.v); rec_d.push_back(R.d); rec_m.push_back(R.m); rec_a.push_back(R.a);
+      nblk_reduced += ((R.flags & kRecHasReproj) ? 1 : 0) + ((R.flags & kRecHasDepth) ? 1 : 0);
+    }
+    L.nrec = (int32_t)rec_cam.size() - L.rec0;
+    L.kv = P->pt_const[p] ? 0 : kv;
+    if (!P->pt_const[p]) { pt_kv[k] = (uint16_t)std::min(kv, 0xfffe); nvarpts += 1; }
+    wl_rows += kv;
+    lhdr.push_back(L);
+  }
+  h->nlong = (int)lhdr.size();
+  h->nrec = (int64_t)rec_cam.size();
+  h->nblocks_reduced = nblk_reduced;
+  if (rec_cam.size() > (size_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "more than 2^31 records on one device");
+  for (int64_t k = h->np_chunked + n_long; k <= h->np; ++k) pt_rec_start[k] = (int32_t)h->nrec;
   {
     double tot[3] = {(double)h->nblocks_total, (double)nblk_reduced, nvarpts};
     if (int rc = allreduce_host(h, tot, 3)) return rc;
@@ -419,6 +455,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_rec_m, rec_m))) return rc;
   if ((rc = dev_upload(&h->d_rec_a, rec_a))) return rc;
   if ((rc = dev_upload(&h->d_pt_rec_start, pt_rec_start))) return rc;
+  if ((rc = dev_upload(&h->d_lhdr, lhdr))) return rc;
+  if ((rc = dev_alloc(&h->d_wl, (size_t)std::max<int64_t>(wl_rows, 1) * 18))) return rc;
   if ((rc = dev_upload(&h->d_blk_desc, blk_desc))) return rc;
   if ((rc = dev_upload(&h->d_blk_ent_start, blk_ent_start))) return rc;
   if ((rc = dev_upload(&h->d_ents, ents))) return rc;
@@ -443,8 +481,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_red, (size_t)h->red_count))) return rc;
   h->d_Sblk = h->d_red; h->d_gc = h->d_red + h->sblk_count; h->d_wv = h->d_gc + h->n; h->d_diagU = h->d_wv + h->n;
   h->d_redsc = h->d_diagU + h->n;
-  if ((rc = dev_alloc(&h->d_part, (size_t)std::max(h->nchunks, 1) * 4))) return rc;
-  if ((rc = dev_alloc(&h->d_part2, (size_t)std::max(h->nchunks, 1) * 8))) return rc;
+  if ((rc = dev_alloc(&h->d_part, (size_t)std::max(h->nchunks + h->nlong, 1) * 4))) return rc;
+  if ((rc = dev_alloc(&h->d_part2, (size_t)std::max(h->nchunks + h->nlong, 1) * 8))) return rc;
   if ((rc = dev_alloc(&h->d_scal, (size_t)U_COUNT))) return rc;
   if ((rc = dev_alloc(&h->d_costpart, (size_t)1024 * 4))) return rc;
   HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * U_COUNT * 2, hipHostMallocDefault));
@@ -489,6 +527,7 @@ static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius) {
   a.pt_rec_start = h->d_pt_rec_start; a.pt_kv = h->d_pt_kv; a.blk_desc = h->d_blk_desc; a.blk_ent_start = h->d_blk_ent_start; a.ents = h->d_ents;
   a.camtab = h->d_camtab; a.pts = h->d_pts; a.ps = h->d_ps; a.loss = h->loss;
   a.radius = radius; a.min_diag = h->opt.min_lm_diagonal; a.max_diag = h->opt.max_lm_diagonal; a.ncv = h->ncv; a.dbg = (g_dbg_flags >> 8) & 0xff;
+  a.lhdr = h->d_lhdr; a.nlong = h->nlong; a.nchunks = h->nchunks; a.cam_slot = h->d_cam_slot; a.wl = h->d_wl;
   a.Sblk = h->d_Sblk; a.gc = h->d_gc; a.wv = h->d_wv; a.diagU = h->d_diagU; a.part = h->d_part; a.diagV = h->d_diagV;
   a.yc = h->d_yc; a.camtab2 = h->d_camtab2; a.pts2 = h->d_pts2; a.part2 = h->d_part2;
   return a;
@@ -536,7 +575,7 @@ static int run_track_sweep(mpsfm_ba_handle* h, double radius) {
   HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double) * (size_t)h->red_count, s));
   SweepArgs a = sweep_args(h, radius);
   launch_track_sweep(a, h->nchunks, false, s);
-  if (h->nchunks > 0) launch_reduce_cols(h->d_part, h->nchunks, 4, 3, 1u << 2, h->d_redsc, s);
+  if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s);
   h->last_radius = radius;
   return 0;
 }
@@ -638,7 +677,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     {
       SweepArgs a = sweep_args(h, radius);
       launch_update_sweep(a, h->nchunks, s);
-      if (h->nchunks > 0) launch_reduce_cols(h->d_part2, h->nchunks, 8, 5, 0u, h->d_scal, s);
+      if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part2, h->nchunks + h->nlong, 8, 5, 0u, h->d_scal, s);
     }
     if (int rc = allreduce_dev(h, h->d_scal, 5)) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_scal + U_X_COST, h->d_redsc, sizeof(double) * 3, hipMemcpyDeviceToDevice, s));
@@ -856,7 +895,7 @@ int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms) {
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   launch_track_sweep(a, h->nchunks, false, h->stream);
   HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-  if (h->nchunks > 0) launch_reduce_cols(h->d_part, h->nchunks, 4, 3, 1u << 2, h->d_redsc, h->stream);
+  if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
   h->last_radius = radius;

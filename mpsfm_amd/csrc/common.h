@@ -47,6 +47,15 @@ struct ChunkHdr {
   int32_t ent0, nent;    // the chunk's pair entries
 };
 
+// A landmark whose track does not fit a chunk (more than kObsMax records or kLocalCamsMax cameras)
+// is swept by a workgroup of its own that strides over the records (k_long_track_sweep).
+struct LongHdr {
+  int32_t rec0, nrec;    // its records (variable cameras first, sorted by slot)
+  int32_t pt;            // re-ordered landmark index
+  int32_t kv;            // records with a variable camera
+  int64_t w0;            // first row of its W scratch (18 doubles per record)
+};
+
 // record meta word: lcam | lpt << 8 | flags << 16
 constexpr uint32_t kRecHasReproj = 1u << 16;
 constexpr uint32_t kRecHasDepth = 1u << 17;
@@ -173,6 +182,11 @@ struct SweepArgs {
   double radius, min_diag, max_diag;
   int32_t ncv;
   int32_t dbg;  // timing-only ablation switches (0 in production)
+  // long tracks
+  const LongHdr* lhdr;
+  int32_t nlong, nchunks;
+  const int32_t* cam_slot;  // [nc] reduced-system slot or -1
+  double* wl;               // W scratch of the long tracks
   // outputs of the track sweep (accumulated, caller zeroes)
   double* Sblk;    // packed upper block triangle, 36 doubles per block
   double* gc;      // [6 ncv] sum Jc^T r

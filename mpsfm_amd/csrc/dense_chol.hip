@@ -116,35 +116,78 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 //   bulk(j-1) a[c] -= t_{j-1} * a_{c,j-1} for c >= j+1 with the column broadcast from LDS; its
 //             reads are issued before chain(j) and consumed after it, hiding the LDS round trip.
 // On return lane i holds row i of L in a[0..i]; s_inv[j] = 1 / L[j][j].
+#define MPSFM_PIN(x) asm volatile("" : "+v"(x))
+
+// bulk(J-1) slot SLOT: up to Q multiply-adds a[c] -= tprev * col[c], c = J+1+SLOT*Q ..
+template <int J, int SLOT, int Q, int NF>
+__device__ __forceinline__ void potrf_bulk(double (&a)[kTile], const double (&col)[kTile], double tprev) {
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    constexpr int kBase = J + 1 + SLOT * Q;
+    if (SLOT * Q + u < NF) {
+      a[kBase + u] -= tprev * col[kBase + u];
+      MPSFM_PIN(a[kBase + u]);
+    }
+  }
+}
+
+// Column J of the register-resident tile Cholesky (see potrf_rows).  Source order == issue order
+// (every value is pinned with an empty volatile asm): the ~11 dependent double-precision ops of
+// chain(J) are interleaved with the independent multiply-adds of bulk(J-1), which a lone wave per
+// SIMD would otherwise issue after the chain instead of inside its latency bubbles.
+template <int J>
+__device__ __forceinline__ void potrf_col(double (&a)[kTile], int lane, double* s_inv, double (*s_col)[kTile], double& tprev,
+                                          bool& ok) {
+  constexpr int NF = (J >= 1) ? (kTile - 1 - J) : 0;  // bulk(J-1) touches c = J+1 .. 31
+  constexpr int Q = (NF + 9) / 10;
+  double col[kTile];
+  if (J >= 1) {
+#pragma unroll
+    for (int c = J + 1; c < kTile; ++c) col[c] = s_col[(J - 1) & 1][c];
+  }
+  const double d = readlane_f64(a[J], J);
+  ok = ok && (d > 0.0) && isfinite(d);
+  double y = __builtin_amdgcn_rsq(d); MPSFM_PIN(y);
+  potrf_bulk<J, 0, Q, NF>(a, col, tprev);
+  double hd = 0.5 * d; MPSFM_PIN(hd);
+  double w = -hd * y; MPSFM_PIN(w);
+  potrf_bulk<J, 1, Q, NF>(a, col, tprev);
+  double e = __builtin_fma(w, y, 1.5); MPSFM_PIN(e);
+  potrf_bulk<J, 2, Q, NF>(a, col, tprev);
+  y = y * e; MPSFM_PIN(y);
+  potrf_bulk<J, 3, Q, NF>(a, col, tprev);
+  w = -hd * y; MPSFM_PIN(w);
+  potrf_bulk<J, 4, Q, NF>(a, col, tprev);
+  e = __builtin_fma(w, y, 1.5); MPSFM_PIN(e);
+  potrf_bulk<J, 5, Q, NF>(a, col, tprev);
+  const double inv = y * e;
+  double t = a[J] * inv; MPSFM_PIN(t);
+  potrf_bulk<J, 6, Q, NF>(a, col, tprev);
+  const double l = t;          // l_iJ = a_iJ / sqrt(d)
+  t = t * inv; MPSFM_PIN(t);   // a_iJ / d
+  potrf_bulk<J, 7, Q, NF>(a, col, tprev);
+  if (J + 1 < kTile) { a[(J + 1) % kTile] -= t * readlane_f64(a[J], (J + 1) % kTile); MPSFM_PIN(a[(J + 1) % kTile]); }
+  potrf_bulk<J, 8, Q, NF>(a, col, tprev);
+  if (lane < kTile) s_col[J & 1][lane] = a[J];
+  if (lane == 0) s_inv[J] = inv;
+  a[J] = l;
+  potrf_bulk<J, 9, Q, NF>(a, col, tprev);
+  tprev = t;
+  if constexpr (J + 1 < kTile) potrf_col<J + 1>(a, lane, s_inv, s_col, tprev, ok);
+}
+
+// Cholesky of a 32x32 tile held one row per lane (lane i and lane i+32 both hold row i).
+// Right-looking, software-pipelined by one column so that the only cross-lane traffic on the
+// dependent chain is two readlane broadcasts:
+//   chain(j)  d = a_jj (readlane), inv = rsqrt(d), t = a_ij / d, the NEXT pivot column gets its
+//             update right away (a[j+1] -= t * a_{j+1,j}, readlane), column j (unscaled) goes to LDS
+//   bulk(j-1) a[c] -= t_{j-1} * a_{c,j-1} for c >= j+1 with the column broadcast from LDS; its
+//             reads are issued before chain(j) and its multiply-adds are slotted between the chain's ops.
+// On return lane i holds row i of L in a[0..i]; s_inv[j] = 1 / L[j][j].
 __device__ __forceinline__ bool potrf_rows(double (&a)[kTile], int lane, double* s_inv, double (*s_col)[kTile]) {
   bool ok = true;
   double tprev = 0.0;
-#pragma unroll
-  for (int j = 0; j < kTile; ++j) {
-    double col[kTile];
-    if (j >= 1) {
-#pragma unroll
-      for (int c = j + 1; c < kTile; ++c) col[c] = s_col[(j - 1) & 1][c];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const double d = readlane_f64(a[j], j);
-    ok = ok && (d > 0.0) && isfinite(d);
-    const double inv = rsqrt_nr(d);
-    const double t = a[j] * inv * inv;
-    if (j + 1 < kTile) a[j + 1] -= t * readlane_f64(a[j], j + 1);
-    if (lane < kTile) s_col[j & 1][lane] = a[j];
-    if (lane == 0) s_inv[j] = inv;
-    a[j] *= inv;
-    __builtin_amdgcn_sched_barrier(0);
-    if (j >= 1) {
-#pragma unroll
-      for (int c = j + 1; c < kTile; ++c) {
-        a[c] -= tprev * col[c];
-        asm volatile("" : "+v"(a[c]));  // materialise now: stops LLVM from deferring these updates
-      }
-    }
-    tprev = t;
-  }
+  potrf_col<0>(a, lane, s_inv, s_col, tprev, ok);
   return ok;
 }
 
@@ -164,14 +207,12 @@ __device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt,
       for (int k = c + 2; k < kTile; ++k) lt[(c + 1) & 1][k] = s_Lt[(c + 1) * kTile + k];
       iv[(c + 1) & 1] = s_inv[c + 1];
     }
-    __builtin_amdgcn_sched_barrier(0);
     x[c] *= iv[c & 1];
 #pragma unroll
     for (int k = c + 1; k < kTile; ++k) {
       x[k] -= x[c] * lt[c & 1][k];
       asm volatile("" : "+v"(x[k]));
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -12,7 +12,7 @@ from mpsfm_amd.problem import BAProblem, Tracks
 from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
 from mpsfm_amd.sfm.mapper.triangulator import MpsfmTriangulator, track_quality, triangulate_points
 from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
-from mpsfm_amd.synthetic import make_config, make_scene
+from mpsfm_amd.synthetic import R_from_quat, make_config, make_scene
 from oracle import cpu_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -196,14 +196,51 @@ def test_edge_cases():
     with pytest.raises(capi.MpsfmHipError) as e:
         capi.ba_solve(bad)
     assert e.value.code == -5
-    # a track longer than one chunk is refused loudly (not silently mishandled)
-    long_prob, _ = make_scene(260, 3, False, seed=1, max_track=260)
-    long_prob.obs_cam = np.concatenate([long_prob.obs_cam, np.arange(260, dtype=np.int32)])
-    long_prob.obs_pt = np.concatenate([long_prob.obs_pt, np.zeros(260, np.int32)])
-    long_prob.obs_xy = np.concatenate([long_prob.obs_xy, np.full((260, 2), 500.0)])
-    with pytest.raises(capi.MpsfmHipError) as e:
-        capi.ba_solve(long_prob)
-    assert e.value.code == -6
+
+
+def test_long_tracks_are_swept_by_their_own_workgroups():
+    """Tracks longer than a chunk (> 192 records or > 64 cameras): every camera sees landmarks 0..2, some
+    cameras twice (two reprojection blocks of one camera on one landmark) and with depth priors."""
+    rng = np.random.default_rng(5)
+    prob, truth = make_scene(260, 400, True, seed=19)
+    R = R_from_quat(truth["cam_quat"])
+    oc, op, oxy, dd, dm, da = [], [], [], [], [], []
+    for pt in range(3):
+        Xc = R @ truth["pts"][pt] + truth["cam_t"]
+        uv = np.stack([1200 * Xc[:, 0] / Xc[:, 2] + 800, 1200 * Xc[:, 1] / Xc[:, 2] + 600], 1) + rng.normal(0, 1, (260, 2))
+        oc.append(np.arange(260)); op.append(np.full(260, pt)); oxy.append(uv)
+        d = Xc[:, 2] * np.exp(rng.normal(0, 0.0263, 260))
+        var = np.maximum((0.0263 * d) ** 2, 0.02**2)
+        dd.append(d); dm.append(d**2 / var); da.append(2 * np.sqrt(var) / d)
+    long_prob = BAProblem(
+        prob.cam_quat, prob.cam_t, prob.pts, prob.cam_intr, prob.cam_intr_idx, prob.pose_const, prob.pt_const,
+        np.concatenate([prob.obs_cam] + oc).astype(np.int32), np.concatenate([prob.obs_pt] + op).astype(np.int32),
+        np.concatenate([prob.obs_xy] + oxy), gauge_axis_cam=prob.gauge_axis_cam,
+        dobs_cam=np.concatenate([prob.dobs_cam] + oc).astype(np.int32), dobs_pt=np.concatenate([prob.dobs_pt] + op).astype(np.int32),
+        dobs_depth=np.concatenate([prob.dobs_depth] + dd), dobs_magnitude=np.concatenate([prob.dobs_magnitude] + dm),
+        dobs_param=np.concatenate([prob.dobs_param] + da), depth_loss_type=prob.depth_loss_type)
+    ref = O.reduced_system(long_prob, radius=50.0)
+    with capi.BAHandle(long_prob.copy()) as h:
+        cr, cd = h.eval_cost()
+        ocr, ocd = O.eval_cost(long_prob)
+        assert cr == pytest.approx(ocr, rel=1e-12) and cd == pytest.approx(ocd, rel=1e-12)
+        h.sweep_once(50.0)
+        S, rhs = h.reduced_system()
+        np.testing.assert_allclose(S, ref["S"], rtol=0, atol=1e-10 * np.abs(ref["S"]).max())
+        np.testing.assert_allclose(rhs, ref["rhs"], rtol=0, atol=1e-10 * np.abs(ref["rhs"]).max())
+    pg, po = long_prob.copy(), long_prob.copy()
+    sg, so = capi.ba_solve(pg), O.solve(po)
+    assert sg["num_iterations"] == so["num_iterations"]
+    assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+    np.testing.assert_allclose(pg.pts[:3], po.pts[:3], atol=1e-6)
+    np.testing.assert_allclose(pg.cam_t, po.cam_t, atol=1e-6)
+    # a constant long-track landmark only feeds the camera blocks
+    cp = long_prob.copy()
+    cp.pt_const[:3] = 1
+    pg, po = cp.copy(), cp.copy()
+    sg, so = capi.ba_solve(pg), O.solve(po)
+    assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+    np.testing.assert_array_equal(pg.pts[:3], cp.pts[:3])
 
 
 def test_full_size_properties_c3():
