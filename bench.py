@@ -54,15 +54,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     keep = None
-    if world > 1:
+    force_dist = os.environ.get("MPSFM_FORCE_DIST") == "1"  # exercise the RCCL hook with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     prob, _ = make_config(args.config, seed=0, shard=rank)
     opts = capi.default_options(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    if world > 1:
+    if dist is not None:
         from mpsfm_amd.dist import make_torch_allreduce
 
         fn, keep = make_torch_allreduce()

@@ -269,3 +269,72 @@ def test_full_size_properties_c3():
         h.set_state(prob)
         s3 = h.solve()
         assert s3["num_iterations"] <= 2 and s3["final_cost"] <= s1["final_cost"] * (1 + 1e-9)
+
+
+@pytest.mark.parametrize("variant", ["trivial_reproj", "cauchy_reproj", "kp_std_2", "two_intrinsics", "shift_logscale", "no_jacobi"])
+def test_solver_variants_match_oracle(variant):
+    prob, _ = make_scene(9, 700, True, seed=41)
+    opts_g, opts_o = capi.default_options(), O.default_options()
+    if variant == "trivial_reproj":
+        prob.reproj_loss_type = 0
+    elif variant == "cauchy_reproj":
+        prob.reproj_loss_type, prob.reproj_loss_scale = 2, 3.0
+    elif variant == "kp_std_2":
+        prob.reproj_loss_scale, prob.reproj_loss_magnitude = 3.0, 0.25
+    elif variant == "two_intrinsics":
+        prob.cam_intr = np.array([[1200.0, 1200.0, 800.0, 600.0], [1210.0, 1190.0, 805.0, 598.0]])
+        prob.cam_intr_idx = (np.arange(prob.n_cams) % 2).astype(np.int32)
+    elif variant == "shift_logscale":
+        prob.shift_logscale = np.stack([np.full(prob.n_cams, 0.01), np.linspace(-0.02, 0.02, prob.n_cams)], 1)
+    elif variant == "no_jacobi":
+        opts_g.jacobi_scaling = 0
+        opts_o.jacobi_scaling = 0
+    pg, po = prob.copy(), prob.copy()
+    sg, so = capi.ba_solve(pg, opts_g), O.solve(po, opts_o)
+    assert sg["initial_cost"] == pytest.approx(so["initial_cost"], rel=1e-12)
+    assert sg["num_iterations"] == so["num_iterations"] and sg["termination"] == so["termination"]
+    assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+    np.testing.assert_allclose(pg.pts, po.pts, atol=1e-6)
+    np.testing.assert_allclose(pg.cam_t, po.cam_t, atol=1e-6)
+
+
+def test_c2_reprojection_only_full_size():
+    """BASELINE config C2: 50 cameras / 20k landmarks, reprojection only — full parity with the oracle."""
+    prob, _ = make_config("C2")
+    pg, po = prob.copy(), prob.copy()
+    sg, so = capi.ba_solve(pg), O.solve(po)
+    assert sg["num_iterations"] == so["num_iterations"]
+    assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+    n = min(len(sg["trace_cost"]), len(so["trace_cost"]))
+    np.testing.assert_allclose(sg["trace_cost"][:n], so["trace_cost"][:n], rtol=1e-9)
+    # a few two-view landmarks with almost no parallax sit ~1e6 away: compare relatively
+    np.testing.assert_allclose(pg.pts, po.pts, rtol=1e-5, atol=1e-6)
+
+
+def test_max_iterations_and_tight_tolerances():
+    prob, _ = make_scene(7, 400, True, seed=43)
+    for kw in (dict(max_num_iterations=3), dict(function_tolerance=1e-12, parameter_tolerance=1e-12, max_num_iterations=80)):
+        pg, po = prob.copy(), prob.copy()
+        sg, so = capi.ba_solve(pg, capi.default_options(**kw)), O.solve(po, O.default_options(**kw))
+        assert sg["num_iterations"] == so["num_iterations"] and sg["termination"] == so["termination"]
+        assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+
+
+def test_rccl_hook_single_rank():
+    """bench.py with a one-rank NCCL(RCCL) process group: the device-buffer all-reduce hook, the
+    zero-copy tensor view and the shared stream are exercised end to end."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPSFM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--kernel-reps", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    ref, _ = make_config("C2")
+    s = capi.ba_solve(ref)
+    assert d["solve"]["final_cost"] == pytest.approx(s["final_cost"], rel=1e-9)
+    assert d["solve"]["lm_iterations"] == s["num_iterations"]
