@@ -163,6 +163,13 @@ struct Blk { int32_t cam; int32_t key; uint8_t kind; int64_t src; };
 // Build the re-ordered, chunked record tables and upload everything.
 static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_state* st) {
   const int nc = P->n_cams, npu = P->n_pts;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (h->opt.verbose < 2) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[mpsfm_ba] build: %-28s %8.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   h->nc = nc; h->np_user = npu;
   h->loss.reproj_type = P->reproj_loss_type; h->loss.reproj_a = P->reproj_loss_scale;
   h->loss.reproj_mag = P->reproj_loss_magnitude; h->loss.depth_type = P->depth_loss_type;
@@ -203,6 +210,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       blks[fill[P->dobs_pt[i]]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 1, i};
     }
   }
+  lap("group blocks by landmark");
   // -- merged records per landmark; fixed blocks aside
   struct Rec { int32_t cam; int32_t slot; uint32_t flags; double u, v, d, m, a; };
   std::vector<Rec> recs; recs.reserve(blks.size());
@@ -248,21 +256,29 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   h->nfixed = (int64_t)fixed.size();
   h->nblocks_total = P->n_obs + P->n_dobs;
 
+  lap("merge records");
   // -- landmark order: those with records sorted by their camera-slot list, then the rest that
   //    are referenced by fixed blocks only
   std::vector<int32_t> order; order.reserve(npu);
   for (int p = 0; p < npu; ++p) if (prec[p + 1] > prec[p]) order.push_back(p);
-  std::sort(order.begin(), order.end(), [&](int a, int b) {
-    const int64_t na = prec[a + 1] - prec[a], nb = prec[b + 1] - prec[b];
-    const int64_t m = std::min<int64_t>(std::min(na, nb), 6);
-    for (int64_t k = 0; k < m; ++k) {
-      const int sa = recs[prec[a] + k].slot < 0 ? INT32_MAX : recs[prec[a] + k].slot;
-      const int sb = recs[prec[b] + k].slot < 0 ? INT32_MAX : recs[prec[b] + k].slot;
-      if (sa != sb) return sa < sb;
+  {
+    // sort key: the first four camera slots of the track (16 bits each; slots beyond 65534 and constant
+    // cameras saturate), then the landmark index — neighbours in this order share cameras
+    std::vector<std::pair<uint64_t, int32_t>> keyed(order.size());
+    for (size_t q = 0; q < order.size(); ++q) {
+      const int pnt = order[q];
+      const int64_t n_p = prec[pnt + 1] - prec[pnt];
+      uint64_t key = 0;
+      for (int64_t k = 0; k < 4; ++k) {
+        uint64_t sk = 0xffff;
+        if (k < n_p && recs[prec[pnt] + k].slot >= 0) sk = (uint64_t)std::min(recs[prec[pnt] + k].slot, 0xfffe);
+        key = (key << 16) | sk;
+      }
+      keyed[q] = {key, pnt};
     }
-    if (na != nb) return na < nb;
-    return a < b;
-  });
+    std::sort(keyed.begin(), keyed.end());
+    for (size_t q = 0; q < order.size(); ++q) order[q] = keyed[q].second;
+  }
   // landmarks whose track does not fit one chunk are swept by a workgroup of their own
   auto is_long = [&](int p) {
     const int64_t r_p = prec[p + 1] - prec[p];
@@ -285,6 +301,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   std::vector<int32_t> inv((size_t)npu + 1, -1);
   for (int64_t k = 0; k < h->np; ++k) inv[order[k]] = (int32_t)k;
 
+  lap("order landmarks");
   // -- chunking
   std::vector<ChunkHdr> chunks;
   std::vector<int32_t> chunk_cams;
@@ -292,7 +309,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   std::vector<uint32_t> blk_desc, ents;          // Schur pairs grouped by destination block, per chunk
   std::vector<int32_t> blk_ent_start;
   struct PairEnt { uint16_t key; uint32_t ent; };
-  std::vector<PairEnt> pe;
+  std::vector<PairEnt> pe, pe_sorted;
   std::vector<std::pair<int, int>> blk_order;    // (count, first index into pe) per block of the open chunk
   std::vector<uint32_t> rec_meta;
   std::vector<uint16_t> pt_kv((size_t)h->np + 1, 0xffff);
@@ -345,8 +362,16 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
         }
       }
       H.nrec = (int32_t)rec_cam.size() - H.rec0;
-      // group the pairs by destination block; heaviest blocks first (they are dealt round-robin to lane groups)
-      std::stable_sort(pe.begin(), pe.end(), [](const PairEnt& a, const PairEnt& b) { return a.key < b.key; });
+      // group the pairs by destination block (counting sort on li*64+lj); heaviest blocks first
+      {
+        static thread_local std::vector<int32_t> cnt;
+        cnt.assign(kLocalCamsMax * kLocalCamsMax + 1, 0);
+        for (const PairEnt& e : pe) cnt[(e.key & 0xff) * kLocalCamsMax + (e.key >> 8) + 1]++;
+        for (size_t q = 1; q < cnt.size(); ++q) cnt[q] += cnt[q - 1];
+        pe_sorted.resize(pe.size());
+        for (const PairEnt& e : pe) pe_sorted[cnt[(e.key & 0xff) * kLocalCamsMax + (e.key >> 8)]++] = e;
+        pe.swap(pe_sorted);
+      }
       blk_order.clear();
       for (size_t i = 0; i < pe.size();) {
         size_t j = i;
@@ -430,6 +455,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     h->nblocks_global = tot[0]; h->nblocks_reduced_global = tot[1]; h->nvarpts_global = tot[2];
   }
 
+  lap("chunks + pair tables");
   // -- fixed records (landmark index re-ordered)
   std::vector<int32_t> fx_cam, fx_pt; std::vector<uint32_t> fx_meta; std::vector<double> fx_xy, fx_d, fx_m, fx_a;
   for (size_t i = 0; i < fixed.size(); ++i) {
@@ -469,6 +495,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_fx_m, fx_m))) return rc;
   if ((rc = dev_upload(&h->d_fx_a, fx_a))) return rc;
 
+  lap("upload tables");
   const size_t ncs = (size_t)std::max(nc, 1), nps = (size_t)std::max<int64_t>(h->np, 1);
   for (double** p : {&h->d_q, &h->d_q2, &h->d_q0}) if ((rc = dev_alloc(p, ncs * 4))) return rc;
   for (double** p : {&h->d_t, &h->d_t2, &h->d_t0}) if ((rc = dev_alloc(p, ncs * 3))) return rc;
@@ -496,6 +523,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   HIP_TRY(hipMemset(h->d_yc, 0, (size_t)std::max(h->n, 1) * sizeof(double)));
   init_tile_tables(h->stream);
   (void)st;
+  lap("allocate work buffers");
   return 0;
 }
 

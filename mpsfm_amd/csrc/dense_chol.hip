@@ -118,9 +118,11 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // On return lane i holds row i of L in a[0..i]; s_inv[j] = 1 / L[j][j].
 #define MPSFM_PIN(x) asm volatile("" : "+v"(x))
 
+constexpr int kPanel = 16;  // columns factored per register panel; the rest of the tile is updated by MFMA
+
 // bulk(J-1) slot SLOT: up to Q multiply-adds a[c] -= tprev * col[c], c = J+1+SLOT*Q ..
 template <int J, int SLOT, int Q, int NF>
-__device__ __forceinline__ void potrf_bulk(double (&a)[kTile], const double (&col)[kTile], double tprev) {
+__device__ __forceinline__ void potrf_bulk(double (&a)[kPanel], const double (&col)[kPanel], double tprev) {
 #pragma unroll
   for (int u = 0; u < Q; ++u) {
     constexpr int kBase = J + 1 + SLOT * Q;
@@ -131,78 +133,118 @@ __device__ __forceinline__ void potrf_bulk(double (&a)[kTile], const double (&co
   }
 }
 
-// Column J of the register-resident tile Cholesky (see potrf_rows).  Source order == issue order
-// (every value is pinned with an empty volatile asm): the ~11 dependent double-precision ops of
-// chain(J) are interleaved with the independent multiply-adds of bulk(J-1), which a lone wave per
-// SIMD would otherwise issue after the chain instead of inside its latency bubbles.
-template <int J>
-__device__ __forceinline__ void potrf_col(double (&a)[kTile], int lane, double* s_inv, double (*s_col)[kTile], double& tprev,
-                                          bool& ok) {
-  constexpr int NF = (J >= 1) ? (kTile - 1 - J) : 0;  // bulk(J-1) touches c = J+1 .. 31
+// Column J of a 16-column register panel (tile columns OFF .. OFF+15; lane i holds row i of the tile,
+// a[c] = A[i][OFF + c]).  Right-looking inside the panel, software-pipelined by one column:
+//   chain(J)  d = pivot (readlane), 1/d by v_rcp_f64 + Newton, t = a_iJ / d, the NEXT pivot column gets
+//             its update right away (readlane), the unscaled column goes to LDS
+//   bulk(J-1) a[c] -= t_{J-1} * a_{OFF+c, J-1} for the remaining panel columns, column broadcast from LDS
+// Source order == issue order (values are pinned with empty volatile asm statements): the dependent
+// ops of chain(J) are interleaved with the independent multiply-adds of bulk(J-1).
+// Publishes column OFF+J of L (s_Lt), 1/L[jj][jj] (s_inv) and the progress counter for the TRSM wave.
+template <int J, int OFF>
+__device__ __forceinline__ void potrf_panel_col(double (&a)[kPanel], int lane, double* s_inv, double (*s_col)[kTile],
+                                                double* s_Lt, int* s_ready, double& tprev, bool& ok) {
+  constexpr int NF = (J >= 1) ? (kPanel - 1 - J) : 0;
   constexpr int Q = (NF + 9) / 10;
-  double col[kTile];
+  double col[kPanel];
   if (J >= 1) {
 #pragma unroll
-    for (int c = J + 1; c < kTile; ++c) col[c] = s_col[(J - 1) & 1][c];
+    for (int c = J + 1; c < kPanel; ++c) col[c] = s_col[(J - 1) & 1][OFF + c];
   }
-  const double d = readlane_f64(a[J], J);
+  const double d = readlane_f64(a[J], OFF + J);
   ok = ok && (d > 0.0) && isfinite(d);
-  double y = __builtin_amdgcn_rsq(d); MPSFM_PIN(y);
+  double r = __builtin_amdgcn_rcp(d); MPSFM_PIN(r);
+  double y = __builtin_amdgcn_rsq(d); MPSFM_PIN(y);          // off-chain: 1/sqrt(d) for L itself
   potrf_bulk<J, 0, Q, NF>(a, col, tprev);
+  double e = __builtin_fma(-d, r, 1.0); MPSFM_PIN(e);
   double hd = 0.5 * d; MPSFM_PIN(hd);
-  double w = -hd * y; MPSFM_PIN(w);
   potrf_bulk<J, 1, Q, NF>(a, col, tprev);
-  double e = __builtin_fma(w, y, 1.5); MPSFM_PIN(e);
+  r = __builtin_fma(r, e, r); MPSFM_PIN(r);
+  double w = -hd * y; MPSFM_PIN(w);
   potrf_bulk<J, 2, Q, NF>(a, col, tprev);
-  y = y * e; MPSFM_PIN(y);
+  e = __builtin_fma(-d, r, 1.0); MPSFM_PIN(e);                // second step: v_rcp_f64 alone is ~2^-26
+  double f = __builtin_fma(w, y, 1.5); MPSFM_PIN(f);
   potrf_bulk<J, 3, Q, NF>(a, col, tprev);
-  w = -hd * y; MPSFM_PIN(w);
+  r = __builtin_fma(r, e, r); MPSFM_PIN(r);
+  y = y * f; MPSFM_PIN(y);
   potrf_bulk<J, 4, Q, NF>(a, col, tprev);
-  e = __builtin_fma(w, y, 1.5); MPSFM_PIN(e);
+  double t = a[J] * r; MPSFM_PIN(t);                          // a_iJ / d
+  w = -hd * y; MPSFM_PIN(w);
   potrf_bulk<J, 5, Q, NF>(a, col, tprev);
-  const double inv = y * e;
-  double t = a[J] * inv; MPSFM_PIN(t);
+  if (J + 1 < kPanel) {
+    a[(J + 1) % kPanel] -= t * readlane_f64(a[J], OFF + (J + 1) % kPanel);
+    MPSFM_PIN(a[(J + 1) % kPanel]);
+  }
+  f = __builtin_fma(w, y, 1.5); MPSFM_PIN(f);
   potrf_bulk<J, 6, Q, NF>(a, col, tprev);
-  const double l = t;          // l_iJ = a_iJ / sqrt(d)
-  t = t * inv; MPSFM_PIN(t);   // a_iJ / d
+  const double inv = y * f;
   potrf_bulk<J, 7, Q, NF>(a, col, tprev);
-  if (J + 1 < kTile) { a[(J + 1) % kTile] -= t * readlane_f64(a[J], (J + 1) % kTile); MPSFM_PIN(a[(J + 1) % kTile]); }
+  const double l = a[J] * inv;                                // l_iJ = a_iJ / sqrt(d)
   potrf_bulk<J, 8, Q, NF>(a, col, tprev);
-  if (lane < kTile) s_col[J & 1][lane] = a[J];
-  if (lane == 0) s_inv[J] = inv;
+  if (lane < kTile) { s_col[J & 1][lane] = a[J]; s_Lt[(OFF + J) * kTile + lane] = l; }
+  if (lane == 0) {
+    s_inv[OFF + J] = inv;
+    // column OFF+J of L and its 1/diag are in LDS: the TRSM wave may use them (DS ops of a wave complete in order)
+    __hip_atomic_store(s_ready, OFF + J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   a[J] = l;
   potrf_bulk<J, 9, Q, NF>(a, col, tprev);
   tprev = t;
-  if constexpr (J + 1 < kTile) potrf_col<J + 1>(a, lane, s_inv, s_col, tprev, ok);
+  if constexpr (J + 1 < kPanel) potrf_panel_col<J + 1, OFF>(a, lane, s_inv, s_col, s_Lt, s_ready, tprev, ok);
 }
 
-// Cholesky of a 32x32 tile held one row per lane (lane i and lane i+32 both hold row i).
-// Right-looking, software-pipelined by one column so that the only cross-lane traffic on the
-// dependent chain is two readlane broadcasts:
-//   chain(j)  d = a_jj (readlane), inv = rsqrt(d), t = a_ij / d, the NEXT pivot column gets its
-//             update right away (a[j+1] -= t * a_{j+1,j}, readlane), column j (unscaled) goes to LDS
-//   bulk(j-1) a[c] -= t_{j-1} * a_{c,j-1} for c >= j+1 with the column broadcast from LDS; its
-//             reads are issued before chain(j) and its multiply-adds are slotted between the chain's ops.
-// On return lane i holds row i of L in a[0..i]; s_inv[j] = 1 / L[j][j].
-__device__ __forceinline__ bool potrf_rows(double (&a)[kTile], int lane, double* s_inv, double (*s_col)[kTile]) {
+// Blocked Cholesky of the 32x32 tile in s_T (row stride 33, both triangles valid) by one wave:
+//   panel 0  columns 0..15 of all 32 rows in registers (factors A11 and solves A21 in one go)
+//   update   A22 -= L21 L21^T with four v_mfma_f64_16x16x4_f64 (operands read back from s_Lt)
+//   panel 1  columns 16..31 (rows 16..31 matter)
+// L^T ends up in s_Lt (s_Lt[c*32 + r] = L[r][c], r >= c), 1/diag in s_inv.
+__device__ __forceinline__ bool potrf_tile(double (*s_T)[kTile + 1], int lane, double* s_inv, double (*s_col)[kTile], double* s_Lt,
+                                           int* s_ready) {
   bool ok = true;
-  double tprev = 0.0;
-  potrf_col<0>(a, lane, s_inv, s_col, tprev, ok);
+  const int row = lane & 31;
+  {
+    double a[kPanel];
+#pragma unroll
+    for (int c = 0; c < kPanel; ++c) a[c] = s_T[row][c];
+    double tprev = 0.0;
+    potrf_panel_col<0, 0>(a, lane, s_inv, s_col, s_Lt, s_ready, tprev, ok);
+  }
+  {
+    const int i = lane & 15, kg = lane >> 4;
+    v4d acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = s_T[kPanel + kg + 4 * r][kPanel + i];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double op = s_Lt[(4 * s + kg) * kTile + kPanel + i];  // L21[i][4s + kg]
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-op, op, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_T[kPanel + kg + 4 * r][kPanel + i] = acc[r];
+  }
+  {
+    double a[kPanel];
+#pragma unroll
+    for (int c = 0; c < kPanel; ++c) a[c] = s_T[row][kPanel + c];
+    double tprev = 0.0;
+    potrf_panel_col<0, kPanel>(a, lane, s_inv, s_col, s_Lt, s_ready, tprev, ok);
+  }
   return ok;
 }
 
-// x <- x L^-T for the row held by this lane; L^T is read from LDS as s_Lt[c*32 + k] = L[k][c]
-// (uniform addresses: broadcast reads), 1/L[c][c] from s_inv.  The reads of column c+1 are issued
-// before the multiply-adds of column c.
-__device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt, const double* s_inv) {
+// x <- x L^-T for the row held by this lane, columns [C0, C1): L^T is read from LDS as
+// s_Lt[c*32 + k] = L[k][c] (uniform addresses: broadcast reads), 1/L[c][c] from s_inv.  The reads of
+// column c+1 are issued before the multiply-adds of column c.
+template <int C0, int C1>
+__device__ __forceinline__ void trsm_cols(double (&x)[kTile], const double* s_Lt, const double* s_inv) {
   double lt[2][kTile];
   double iv[2];
 #pragma unroll
-  for (int k = 1; k < kTile; ++k) lt[0][k] = s_Lt[k];
-  iv[0] = s_inv[0];
+  for (int k = C0 + 1; k < kTile; ++k) lt[C0 & 1][k] = s_Lt[C0 * kTile + k];
+  iv[C0 & 1] = s_inv[C0];
 #pragma unroll
-  for (int c = 0; c < kTile; ++c) {
-    if (c + 1 < kTile) {
+  for (int c = C0; c < C1; ++c) {
+    if (c + 1 < C1) {
 #pragma unroll
       for (int k = c + 2; k < kTile; ++k) lt[(c + 1) & 1][k] = s_Lt[(c + 1) * kTile + k];
       iv[(c + 1) & 1] = s_inv[c + 1];
@@ -216,11 +258,16 @@ __device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt,
   }
 }
 
-// One step of the right-looking factorisation.  j = -1: factor tile column 0 only.  Otherwise:
-// every trailing tile (ti >= tk > j) gets  A[ti][tk] -= L[ti][j] L[tk][j]^T  and the tiles of column
-// j+1 are turned into L right away: each of those waves re-derives the updated diagonal tile,
-// factors it in registers and solves its own tile against it.  The wave that owns the diagonal
-// tile also stores L^-T of it (LinvT) for the back substitution.
+// The solve runs BEHIND the factorising wave: the first 16 columns (76 % of the multiply-adds) start
+// as soon as the progress counter says columns 0..15 of L are in LDS, i.e. under the second half of
+// the factorisation; only the last 16 columns wait for the factor to be complete.
+__device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt, const double* s_inv, int* s_ready) {
+  while (__hip_atomic_load(s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kTile / 2) __builtin_amdgcn_s_sleep(2);
+  trsm_cols<0, kTile / 2>(x, s_Lt, s_inv);
+  while (__hip_atomic_load(s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kTile) __builtin_amdgcn_s_sleep(2);
+  trsm_cols<kTile / 2, kTile>(x, s_Lt, s_inv);
+}
+
 // half-tile variants (rows 16 mi .. 16 mi + 15) for the two waves of a trailing-update workgroup
 __device__ __forceinline__ void half_load_acc(const double* __restrict__ T, int lane, int mi, v4d acc[2]) {
 #pragma unroll
@@ -270,6 +317,7 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
   __shared__ double s_Lt[kTile * kTile];
   __shared__ double s_inv[kTile];
   __shared__ double s_col[2][kTile];
+  __shared__ int s_ready;  // columns of L published by the factorising wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tk = j + 1 + blockIdx.y;
   const int ti = j + 1 + blockIdx.x;
@@ -285,6 +333,7 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
   // ---- panel column j+1 -------------------------------------------------------------------
   const int row = lane & 31;
   const bool diag = (ti == tk);
+  if (threadIdx.x == 0) s_ready = 0;
   if (wave == 0) {
     // updated diagonal tile -> s_T
     v4d dacc[2][2];
@@ -305,19 +354,14 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
   __syncthreads();
   double x[kTile];
   if (wave == 0) {
-    double a[kTile];
-#pragma unroll
-    for (int c = 0; c < kTile; ++c) a[c] = s_T[row][c];
     bool ok = true;
-    if (!(dbg & 1)) ok = potrf_rows(a, lane, s_inv, s_col);
-    if (lane < kTile) {
-#pragma unroll
-      for (int c = 0; c < kTile; ++c) s_Lt[c * kTile + lane] = a[c];
-    }
-    if (diag && lane < kTile) {
-      double2* dst = reinterpret_cast<double2*>(C + lane * kTile);
-#pragma unroll
-      for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(c <= lane ? a[c] : 0.0, c + 1 <= lane ? a[c + 1] : 0.0);
+    if (!(dbg & 1)) ok = potrf_tile(s_T, lane, s_inv, s_col, s_Lt, &s_ready);
+    else if (lane == 0) __hip_atomic_store(&s_ready, kTile, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (diag) {
+      for (int e = lane; e < kTileElems; e += 64) {
+        const int r = e >> 5, c = e & 31;
+        C[e] = (c <= r) ? s_Lt[c * kTile + r] : 0.0;
+      }
     }
     if (diag && !ok && lane == 0) atomicExch(fail, 1);
   } else {
@@ -328,10 +372,7 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
 #pragma unroll
       for (int c = 0; c < kTile; ++c) x[c] = s_X[row][c];
     }
-  }
-  __syncthreads();
-  if (wave == 1) {
-    if (!(dbg & 2)) trsm_row(x, s_Lt, s_inv);
+    if (!(dbg & 2)) trsm_row(x, s_Lt, s_inv, &s_ready);
     if (lane < kTile) {
       double2* dst = diag ? reinterpret_cast<double2*>(LinvT + (size_t)tk * kTileElems + lane * kTile)
                           : reinterpret_cast<double2*>(C + lane * kTile);
