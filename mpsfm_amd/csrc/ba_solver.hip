@@ -262,22 +262,29 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   std::vector<int32_t> order; order.reserve(npu);
   for (int p = 0; p < npu; ++p) if (prec[p + 1] > prec[p]) order.push_back(p);
   {
-    // sort key: the first four camera slots of the track (16 bits each; slots beyond 65534 and constant
-    // cameras saturate), then the landmark index — neighbours in this order share cameras
-    std::vector<std::pair<uint64_t, int32_t>> keyed(order.size());
+    // sort key: the first six camera slots of the track (16 bits each; slots beyond 65534 and constant
+    // cameras saturate), then the track length, then the landmark index — neighbours in this order share
+    // cameras, which keeps the set of S blocks a chunk touches small
+    struct Key { uint64_t k1, k2; int32_t p; };
+    std::vector<Key> keyed(order.size());
     for (size_t q = 0; q < order.size(); ++q) {
       const int pnt = order[q];
       const int64_t n_p = prec[pnt + 1] - prec[pnt];
-      uint64_t key = 0;
-      for (int64_t k = 0; k < 4; ++k) {
+      uint64_t key[2] = {0, 0};
+      for (int64_t k = 0; k < 6; ++k) {
         uint64_t sk = 0xffff;
         if (k < n_p && recs[prec[pnt] + k].slot >= 0) sk = (uint64_t)std::min(recs[prec[pnt] + k].slot, 0xfffe);
-        key = (key << 16) | sk;
+        key[k / 4] = (key[k / 4] << 16) | sk;
       }
-      keyed[q] = {key, pnt};
+      key[1] = (key[1] << 32) | (uint64_t)std::min<int64_t>(n_p, 0xffffffff);
+      keyed[q] = Key{key[0], key[1], pnt};
     }
-    std::sort(keyed.begin(), keyed.end());
-    for (size_t q = 0; q < order.size(); ++q) order[q] = keyed[q].second;
+    std::sort(keyed.begin(), keyed.end(), [](const Key& a, const Key& b) {
+      if (a.k1 != b.k1) return a.k1 < b.k1;
+      if (a.k2 != b.k2) return a.k2 < b.k2;
+      return a.p < b.p;
+    });
+    for (size_t q = 0; q < order.size(); ++q) order[q] = keyed[q].p;
   }
   // landmarks whose track does not fit one chunk are swept by a workgroup of their own
   auto is_long = [&](int p) {
@@ -384,10 +391,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       H.blk0 = (int32_t)blk_desc.size();
       H.ent0 = (int32_t)ents.size();
       H.nent = (int32_t)pe.size();
+      // block-major: all items of a block are neighbours, so the flush combines them (one atomic pass per
+      // block and round); blocks are already ordered heaviest first
       std::vector<std::pair<int, int>> items;  // (count, first index into pe)
       for (const auto& bo : blk_order)
         for (int t = 0; t < bo.first; t += kItemPairs) items.emplace_back(std::min(kItemPairs, bo.first - t), bo.second + t);
-      std::stable_sort(items.begin(), items.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
       H.nblk = (int32_t)items.size();
       for (const auto& it : items) {
         blk_desc.push_back(pe[it.second].key);

@@ -14,13 +14,13 @@ namespace mpsfm {
 #define MPSFM_TILE_CAMS 16
 #endif
 #ifndef MPSFM_ITEM_PAIRS
-#define MPSFM_ITEM_PAIRS 1000000
+#define MPSFM_ITEM_PAIRS 16
 #endif
 #ifndef MPSFM_ENT_STAGE
 #define MPSFM_ENT_STAGE 1024
 #endif
 #ifndef MPSFM_OBS_MAX
-#define MPSFM_OBS_MAX 192
+#define MPSFM_OBS_MAX 256
 #endif
 
 // ---- track-sweep chunk geometry ----------------------------------------------------------
