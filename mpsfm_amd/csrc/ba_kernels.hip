@@ -801,12 +801,15 @@ __global__ __launch_bounds__(kThreads) void k_cost_records(CostArgs A) {
 }
 
 // deterministic column sums (or max for columns flagged in max_mask) of a [rows][stride] array
-__global__ __launch_bounds__(kThreads) void k_reduce_cols(const double* part, int64_t rows, int stride, int ncols,
-                                                          uint32_t max_mask, double* out) {
-  // fixed summation order (thread-strided rows, wave tree, 4 waves): deterministic run to run
-  __shared__ double s[8 * (kThreads / 64)];
+constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void k_reduce_cols(const double* part, int64_t rows, int stride, int ncols,
+                                                                uint32_t max_mask, double* out, double* out2) {
+  // fixed summation order (thread-strided rows, wave tree, then the 16 wave results in order):
+  // deterministic run to run.  out2 (optional) receives a second copy.
+  constexpr int kWaves = kReduceThreads / 64;
+  __shared__ double s[8 * kWaves];
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t r = threadIdx.x; r < rows; r += kThreads) {
+  for (int64_t r = threadIdx.x; r < rows; r += kReduceThreads) {
 #pragma unroll
     for (int c = 0; c < 8; ++c)
       if (c < ncols) {
@@ -818,12 +821,16 @@ __global__ __launch_bounds__(kThreads) void k_reduce_cols(const double* part, in
   for (int c = 0; c < 8; ++c)
     if (c < ncols) {
       const double w = ((max_mask >> c) & 1u) ? wave_max(v[c]) : wave_sum(v[c]);
-      if ((threadIdx.x & 63) == 0) s[c * 4 + (threadIdx.x >> 6)] = w;
+      if ((threadIdx.x & 63) == 0) s[c * kWaves + (threadIdx.x >> 6)] = w;
     }
   __syncthreads();
   if ((int)threadIdx.x < ncols) {
-    const double* p = &s[threadIdx.x * 4];
-    out[threadIdx.x] = ((max_mask >> threadIdx.x) & 1u) ? fmax(fmax(p[0], p[1]), fmax(p[2], p[3])) : (p[0] + p[1]) + (p[2] + p[3]);
+    const double* p = &s[threadIdx.x * kWaves];
+    const bool is_max = (max_mask >> threadIdx.x) & 1u;
+    double r = p[0];
+    for (int w = 1; w < kWaves; ++w) r = is_max ? fmax(r, p[w]) : r + p[w];
+    out[threadIdx.x] = r;
+    if (out2) out2[threadIdx.x] = r;
   }
 }
 
@@ -864,7 +871,8 @@ __global__ void k_pt_scales(int64_t n3, const uint16_t* pt_kv, const double* dia
 // Single workgroup (cameras are few); writes scal[U_STEP_SQ_CAMS], [U_XN_SQ_CAMS], [U_GMAX_CAMS].
 __global__ __launch_bounds__(kThreads) void k_cam_update(int nc, const int32_t* cam_slot, const double* q,
                                                          const double* t, const double* cs, const double* yc,
-                                                         const double* gc, double* q2, double* t2, double* scal) {
+                                                         const double* gc, double* q2, double* t2, double* scal,
+                                                         const double* intr, const int32_t* intr_idx, double* camtab2) {
   __shared__ double s_red[3 * (kThreads / 64)];
   double step = 0.0, xn = 0.0, gmax = 0.0;
   for (int i = threadIdx.x; i < nc; i += kThreads) {
@@ -896,6 +904,15 @@ __global__ __launch_bounds__(kThreads) void k_cam_update(int nc, const int32_t* 
     }
     for (int k = 0; k < 4; ++k) q2[4 * i + k] = qn[k];
     for (int k = 0; k < 3; ++k) t2[3 * i + k] = tn[k];
+    if (camtab2) {  // candidate camera table row (what k_build_camtab would write)
+      double* o = camtab2 + (size_t)i * kCamRec;
+      quat_to_R(qn, o);
+      o[9] = tn[0]; o[10] = tn[1]; o[11] = tn[2];
+      const double* K = intr + 4 * intr_idx[i];
+      o[12] = K[0]; o[13] = K[1]; o[14] = K[2]; o[15] = K[3];
+      for (int k = 0; k < 6; ++k) o[16 + k] = cs[6 * i + k];
+      o[22] = o[23] = 0.0;
+    }
   }
   step = wave_sum(step); xn = wave_sum(xn); gmax = wave_max(gmax);
   const int w = threadIdx.x >> 6;
@@ -942,8 +959,8 @@ void launch_cost_records(const CostArgs& a, int nblocks, hipStream_t s) {
   hipLaunchKernelGGL(k_cost_records, dim3(nblocks), dim3(kThreads), 0, s, a);
 }
 void launch_reduce_cols(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out,
-                        hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(kThreads), 0, s, part, rows, stride, ncols, max_mask, out);
+                        hipStream_t s, double* out2) {
+  hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(kReduceThreads), 0, s, part, rows, stride, ncols, max_mask, out, out2);
 }
 void launch_build_camtab(int nc, const double* q, const double* t, const double* intr, const int32_t* intr_idx,
                          const double* cs, double* camtab, hipStream_t s) {
@@ -961,8 +978,10 @@ void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, in
   hipLaunchKernelGGL(k_pt_scales, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, s, n3, pt_kv, diagV, jacobi, ps);
 }
 void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs,
-                       const double* yc, const double* gc, double* q2, double* t2, double* scal, hipStream_t s) {
-  hipLaunchKernelGGL(k_cam_update, dim3(1), dim3(kThreads), 0, s, nc, cam_slot, q, t, cs, yc, gc, q2, t2, scal);
+                       const double* yc, const double* gc, double* q2, double* t2, double* scal, hipStream_t s,
+                       const double* intr, const int32_t* intr_idx, double* camtab2) {
+  hipLaunchKernelGGL(k_cam_update, dim3(1), dim3(kThreads), 0, s, nc, cam_slot, q, t, cs, yc, gc, q2, t2, scal, intr, intr_idx,
+                     camtab2);
 }
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t s) {
   hipLaunchKernelGGL(k_pts_sqnorm, dim3(nblocks), dim3(kThreads), 0, s, np, pt_kv, pts, part);

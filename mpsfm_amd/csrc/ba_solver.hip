@@ -21,13 +21,15 @@ void init_tile_tables(hipStream_t);
 void launch_track_sweep(const SweepArgs&, int nchunks, bool diag_only, hipStream_t);
 void launch_update_sweep(const SweepArgs&, int nchunks, hipStream_t);
 void launch_cost_records(const CostArgs&, int nblocks, hipStream_t);
-void launch_reduce_cols(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out, hipStream_t);
+void launch_reduce_cols(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out, hipStream_t,
+                        double* out2 = nullptr);
 void launch_build_camtab(int nc, const double* q, const double* t, const double* intr, const int32_t* intr_idx,
                          const double* cs, double* camtab, hipStream_t);
 void launch_cam_scales(int nc, const int32_t* cam_slot, const double* cmask, const double* diagU, int jacobi, double* cs, hipStream_t);
 void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, int jacobi, double* ps, hipStream_t);
 void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs, const double* yc,
-                       const double* gc, double* q2, double* t2, double* scal, hipStream_t);
+                       const double* gc, double* q2, double* t2, double* scal, hipStream_t, const double* intr = nullptr,
+                       const int32_t* intr_idx = nullptr, double* camtab2 = nullptr);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
 void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t);
@@ -611,7 +613,8 @@ static int run_track_sweep(mpsfm_ba_handle* h, double radius) {
   HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double) * (size_t)h->red_count, s));
   SweepArgs a = sweep_args(h, radius);
   launch_track_sweep(a, h->nchunks, false, s);
-  if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s);
+  if (h->nchunks + h->nlong > 0)
+    launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, h->opt.allreduce ? nullptr : h->d_scal + U_X_COST);
   h->last_radius = radius;
   return 0;
 }
@@ -708,15 +711,16 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     HIP_TRY(hipEventRecord(h->ev[1], s));
     if (int rc = run_dense(h, radius)) return rc;
     HIP_TRY(hipEventRecord(h->ev[2], s));
-    launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s);
-    launch_build_camtab(h->nc, h->d_q2, h->d_t2, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab2, s);
+    launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s,
+                      h->d_intr, h->d_intr_idx, h->d_camtab2);
     {
       SweepArgs a = sweep_args(h, radius);
       launch_update_sweep(a, h->nchunks, s);
       if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part2, h->nchunks + h->nlong, 8, 5, 0u, h->d_scal, s);
     }
     if (int rc = allreduce_dev(h, h->d_scal, 5)) return rc;
-    HIP_TRY(hipMemcpyAsync(h->d_scal + U_X_COST, h->d_redsc, sizeof(double) * 3, hipMemcpyDeviceToDevice, s));
+    if (h->opt.allreduce)  // the all-reduced scalars of the track sweep (single rank: written by its reduction directly)
+      HIP_TRY(hipMemcpyAsync(h->d_scal + U_X_COST, h->d_redsc, sizeof(double) * 3, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipEventRecord(h->ev[3], s));
     HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * U_COUNT, hipMemcpyDeviceToHost, s));
     int h_fail = 0;
