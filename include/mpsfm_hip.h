@@ -228,6 +228,48 @@ int mpsfm_filter_tracks(const mpsfm_tracks* tracks, const double* xyz /* [n_trac
                         int32_t device, double* max_tri_angle /* [n_tracks] */,
                         double* el_sq_err /* [n_el] */, uint8_t* el_front /* [n_el] */);
 
+/* -- depth-from-normals integration: replaces the per-image solve of Image.integrate()
+ *    (mpsfm/sfm/scene/image/integration.py:133-137 -> _integrate :383-520): IRLS over a 5-point SPD
+ *    system on the H*W log-depths with Jacobi-preconditioned CG (scipy/cupy `cg` semantics), bilateral
+ *    weights sigmoid(k ((A2 z)^2 - (A1 z)^2)), depth-prior and sparse-depth terms.  Maps are row-major
+ *    [H][W]; `normals` is [H][W][3] in the reference's channel order (nx = ch 1, ny = ch 0, nz = -ch 2,
+ *    :273-275); `normals_var` holds the diagonal (00, 11, 22) of the per-pixel normal covariance. ---- */
+#define MPSFM_INT_MAX_IRLS 16
+typedef struct mpsfm_int_problem {
+  int32_t H, W;
+  const double* depth_prior;        /* depth.data_prior                                   */
+  const double* depth_uncertainty;  /* depth.uncertainty (variance)                       */
+  const uint8_t* valid;             /* depth.valid                                        */
+  const double* normals;            /* normals.data                                       */
+  const double* normals_var;        /* diag of normals.uncertainty                        */
+  const double* depth_init;         /* depth.data: the map being refined (checkpoint)     */
+  double K[4];                      /* (K[1,1] sy, K[0,0] sx, K[1,2] sy, K[0,2] sx), :118-124 */
+  int32_t n_sparse;                 /* sparse 3-D points projected into the map (:99-116) */
+  const int32_t* sparse_x; const int32_t* sparse_y;
+  const double* sparse_depth3d; const double* sparse_zvar;
+  /* Image.default_conf (mpsfm/sfm/scene/image/base.py:30-55) */
+  double large_number, tol, step_size, cg_tol, lambda1, lambda2, k;
+  double depth_magnitude_multiplier, normals_magnitude_multiplier, scale_filter_factor;
+  int32_t max_iter, cg_max_iter, scale_filter;
+  /* state the reference caches on the image between calls (IntVars, :18-29) */
+  int32_t init;                     /* _integrate(init=...)                                */
+  int32_t integrated;               /* in                                                  */
+  double energy_old;                /* in                                                  */
+  double* wu; double* wv;           /* [H*W] in (when init && integrated) / out, may be NULL */
+} mpsfm_int_problem;
+
+typedef struct mpsfm_int_summary {
+  int32_t changed;                  /* 1: depth_out holds the new map; 0: frame skipped     */
+  int32_t irls_iterations, cg_iterations_total, integrated_out;
+  double energy_initial, energy_final, energy_old_out;
+  int32_t cg_iters[MPSFM_INT_MAX_IRLS];
+  double energies[MPSFM_INT_MAX_IRLS + 1];
+  float ms;                         /* device time of the solve (HIP events)                */
+} mpsfm_int_summary;
+
+int mpsfm_integrate_depth(const mpsfm_int_problem* problem, int32_t device, double* depth_out /* [H*W] */,
+                          mpsfm_int_summary* summary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,7 @@ EXPORTS = [
     "mpsfm_ba_solve_resident", "mpsfm_ba_get_state", "mpsfm_ba_destroy", "mpsfm_ba_eval_cost",
     "mpsfm_ba_sweep_once", "mpsfm_ba_get_reduced_system", "mpsfm_ba_reduced_dim",
     "mpsfm_ba_get_dense_solution", "mpsfm_ba_dense_solve_once", "mpsfm_point_covs",
-    "mpsfm_triangulate_tracks", "mpsfm_filter_tracks",
+    "mpsfm_triangulate_tracks", "mpsfm_filter_tracks", "mpsfm_integrate_depth",
 ]
 
 _lib = None
@@ -207,3 +207,53 @@ def filter_tracks(tr: Tracks, xyz: np.ndarray, device: int = 0):
     ct = tr.c_tracks()
     _check(lib().mpsfm_filter_tracks(C.byref(ct), xyz.ctypes.data, device, ang.ctypes.data, err.ctypes.data, front.ctypes.data))
     return ang, err, front.astype(bool)
+
+
+INT_DEFAULT_CONF = dict(
+    large_number=1e6, max_iter=10, tol=5e-2, step_size=1, cg_max_iter=5000, cg_tol=1e-3, lambda1=1, lambda2=1, k=1,
+    depth_magnitude_multiplier=1, normals_magnitude_multiplier=1, scale_filter=True, scale_filter_factor=1.5,
+)
+
+
+def integrate_depth(depth_prior, depth_uncertainty, valid, normals, normals_var, depth_init, K, kps, depth3d, zvars3d,
+                    conf=None, init=True, integrated=False, energy_old=0.0, wu=None, wv=None, device=0):
+    """mpsfm_integrate_depth.  Returns (depth map or None, summary dict, wu, wv)."""
+    from .problem import CIntProblem, CIntSummary
+
+    c = dict(INT_DEFAULT_CONF)
+    c.update(conf or {})
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)  # noqa: E731
+    depth_prior, depth_uncertainty, depth_init = f64(depth_prior), f64(depth_uncertainty), f64(depth_init)
+    H, W = depth_prior.shape
+    valid = np.ascontiguousarray(valid, np.uint8)
+    normals, normals_var = f64(normals).reshape(H, W, 3), f64(normals_var).reshape(H, W, 3)
+    kps = np.ascontiguousarray(kps, np.int64).reshape(-1, 2)
+    sx, sy = np.ascontiguousarray(kps[:, 0], np.int32), np.ascontiguousarray(kps[:, 1], np.int32)
+    depth3d, zvars3d = f64(depth3d), f64(zvars3d)
+    wu = np.zeros(H * W) if wu is None else f64(wu).copy()
+    wv = np.zeros(H * W) if wv is None else f64(wv).copy()
+    P = CIntProblem()
+    P.H, P.W = H, W
+    P.depth_prior, P.depth_uncertainty, P.valid = depth_prior.ctypes.data, depth_uncertainty.ctypes.data, valid.ctypes.data
+    P.normals, P.normals_var, P.depth_init = normals.ctypes.data, normals_var.ctypes.data, depth_init.ctypes.data
+    P.K = (C.c_double * 4)(*[float(v) for v in K])
+    P.n_sparse = len(sx)
+    P.sparse_x, P.sparse_y = (sx.ctypes.data, sy.ctypes.data) if len(sx) else (None, None)
+    P.sparse_depth3d, P.sparse_zvar = (depth3d.ctypes.data, zvars3d.ctypes.data) if len(sx) else (None, None)
+    for k in ("large_number", "tol", "step_size", "cg_tol", "lambda1", "lambda2", "k", "depth_magnitude_multiplier",
+              "normals_magnitude_multiplier", "scale_filter_factor"):
+        setattr(P, k, float(c[k]))
+    P.max_iter, P.cg_max_iter, P.scale_filter = int(c["max_iter"]), int(c["cg_max_iter"]), int(bool(c["scale_filter"]))
+    P.init, P.integrated, P.energy_old = int(bool(init)), int(bool(integrated)), float(energy_old or 0.0)
+    P.wu, P.wv = wu.ctypes.data, wv.ctypes.data
+    out = np.zeros((H, W))
+    S = CIntSummary()
+    L = lib()
+    L.mpsfm_integrate_depth.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    _check(L.mpsfm_integrate_depth(C.byref(P), device, out.ctypes.data, C.byref(S)))
+    n = S.irls_iterations
+    summary = dict(changed=bool(S.changed), irls_iterations=n, cg_iterations_total=S.cg_iterations_total,
+                   integrated=bool(S.integrated_out), energy_old=S.energy_old_out, energy_initial=S.energy_initial,
+                   energy_final=S.energy_final, cg_iters=[S.cg_iters[i] for i in range(n)],
+                   energies=[S.energies[i] for i in range(n + 1)], ms=S.ms)
+    return (out if S.changed else None), summary, wu, wv

@@ -332,3 +332,29 @@ class Tracks:
         t.cam_intr, t.cam_intr_idx = _ptr(self.cam_intr), _ptr(self.cam_intr_idx)
         t.track_start, t.el_cam, t.el_xy = _ptr(self.track_start), _ptr(self.el_cam), _ptr(self.el_xy)
         return t
+
+
+INT_MAX_IRLS = 16
+
+
+class CIntProblem(C.Structure):
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32),
+        ("depth_prior", C.c_void_p), ("depth_uncertainty", C.c_void_p), ("valid", C.c_void_p), ("normals", C.c_void_p),
+        ("normals_var", C.c_void_p), ("depth_init", C.c_void_p), ("K", C.c_double * 4),
+        ("n_sparse", C.c_int32), ("sparse_x", C.c_void_p), ("sparse_y", C.c_void_p), ("sparse_depth3d", C.c_void_p),
+        ("sparse_zvar", C.c_void_p),
+        ("large_number", C.c_double), ("tol", C.c_double), ("step_size", C.c_double), ("cg_tol", C.c_double),
+        ("lambda1", C.c_double), ("lambda2", C.c_double), ("k", C.c_double), ("depth_magnitude_multiplier", C.c_double),
+        ("normals_magnitude_multiplier", C.c_double), ("scale_filter_factor", C.c_double),
+        ("max_iter", C.c_int32), ("cg_max_iter", C.c_int32), ("scale_filter", C.c_int32),
+        ("init", C.c_int32), ("integrated", C.c_int32), ("energy_old", C.c_double), ("wu", C.c_void_p), ("wv", C.c_void_p),
+    ]
+
+
+class CIntSummary(C.Structure):
+    _fields_ = [
+        ("changed", C.c_int32), ("irls_iterations", C.c_int32), ("cg_iterations_total", C.c_int32), ("integrated_out", C.c_int32),
+        ("energy_initial", C.c_double), ("energy_final", C.c_double), ("energy_old_out", C.c_double),
+        ("cg_iters", C.c_int32 * INT_MAX_IRLS), ("energies", C.c_double * (INT_MAX_IRLS + 1)), ("ms", C.c_float),
+    ]

@@ -1,0 +1,22 @@
+"""Times the depth-from-normals integration (row f1) at the reference's map size: HIP vs the SciPy oracle."""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from mpsfm_amd import capi
+from mpsfm_amd.synthetic_maps import make_maps
+from oracle import integration_oracle as IO
+
+maps = make_maps(290, 387, seed=8, n_sparse=1500)
+nu = maps["normals_uncertainty"]
+nvar = np.stack([nu[..., 0, 0], nu[..., 1, 1], nu[..., 2, 2]], -1)
+args = (maps["depth_prior"], maps["depth_uncertainty"], maps["valid"], maps["normals"], nvar, maps["depth_init"], maps["K"],
+        maps["kps"], maps["depth3d"], maps["zvars3d"])
+for i in range(3):
+    t0 = time.perf_counter(); d, s, *_ = capi.integrate_depth(*args); t1 = time.perf_counter()
+    print(f"hip: wall {1e3*(t1-t0):.1f} ms, device {s['ms']:.2f} ms, irls {s['irls_iterations']}, cg {s['cg_iters']}", flush=True)
+keys = ("depth_prior", "depth_uncertainty", "valid", "normals", "normals_uncertainty", "depth_init", "K", "kps", "depth3d", "zvars3d")
+t0 = time.perf_counter(); do, ch, st, info = IO.integrate(IO.IntInputs(**{k: maps[k] for k in keys})); t1 = time.perf_counter()
+print(f"oracle (scipy cg): {1e3*(t1-t0):.1f} ms, cg {info['cg_iters']}; max rel diff {np.max(np.abs(d/do-1)):.2e}")
+# algorithmic bytes of one CG iteration: 5-point stencil on N doubles: read d,cr,cd (3), zz,p (2+halo), write p,q (2); update: read p,q,r,z,minv (5) write z,r,zz (3)
+N = 290 * 387
+print("bytes per CG iteration (algorithmic):", 15 * 8 * N, "-> GB/s at measured rate:", 15 * 8 * N * sum(s['cg_iters']) / (s['ms'] * 1e-3) / 1e9)

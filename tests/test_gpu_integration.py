@@ -1,0 +1,105 @@
+"""GPU parity of the depth-from-normals integration: HIP stencil IRLS/PCG vs the
+NumPy/SciPy oracle on the same inputs — energies, CG iteration counts and the integrated depth map."""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from mpsfm_amd import capi
+from mpsfm_amd.synthetic_maps import make_maps
+from oracle import integration_oracle as IO
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("depth_prior", "depth_uncertainty", "valid", "normals", "normals_uncertainty", "depth_init", "K", "kps", "depth3d", "zvars3d")
+
+
+def _oracle(maps, state=None, **conf):
+    c = dict(IO.DEFAULT_CONF)
+    c.update(conf)
+    return IO.integrate(IO.IntInputs(**{k: maps[k] for k in KEYS}, conf=c), state)
+
+
+def _hip(maps, **kw):
+    nu = maps["normals_uncertainty"]
+    nvar = np.stack([nu[..., 0, 0], nu[..., 1, 1], nu[..., 2, 2]], -1)
+    return capi.integrate_depth(maps["depth_prior"], maps["depth_uncertainty"], maps["valid"], maps["normals"], nvar,
+                                maps["depth_init"], maps["K"], maps["kps"], maps["depth3d"], maps["zvars3d"], **kw)
+
+
+def _compare(maps, conf=None):
+    depth_o, changed_o, state, info = _oracle(maps, **(conf or {}))
+    depth_g, s, wu, wv = _hip(maps, conf=conf)
+    assert s["changed"] == changed_o
+    n = min(len(s["energies"]), len(info["energies"]))
+    assert len(s["energies"]) == len(info["energies"])
+    np.testing.assert_allclose(s["energies"][:n], info["energies"][:n], rtol=1e-6)
+    # CG stops on |r| < rtol |b|: allow the count to differ by a step where the residual sits on the threshold
+    assert all(abs(a - b) <= max(1, 0.02 * b) for a, b in zip(s["cg_iters"], info["cg_iters"]))
+    if changed_o:
+        np.testing.assert_allclose(depth_g, depth_o, rtol=2e-4)
+        np.testing.assert_allclose(wu, state.wu, atol=2e-3)
+    return depth_g, s, wu, wv, state
+
+
+def test_golden_case():
+    z = np.load(os.path.join(GOLDEN, "integration_case_24x32.npz"))
+    maps = {k: z[k] for k in z.files}
+    maps["K"] = tuple(z["K"])
+    depth, s, *_ = _compare(maps)
+    np.testing.assert_allclose(depth, z["out_depth"], rtol=2e-4)
+    np.testing.assert_allclose(s["energies"], z["energies"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape,seed", [((48, 64), 1), ((97, 129), 2), ((33, 20), 3)])
+def test_matches_oracle(shape, seed):
+    maps = make_maps(shape[0], shape[1], seed=seed, n_sparse=150)
+    depth, s, *_ = _compare(maps)
+    e0 = np.median(np.abs(np.log(maps["depth_prior"] / maps["depth_true"])))
+    e1 = np.median(np.abs(np.log(depth / maps["depth_true"])))
+    assert e1 < e0 and s["energy_final"] < 0.1 * s["energy_initial"]
+
+
+def test_conf_variants_and_edge_cases():
+    maps = make_maps(40, 52, seed=5, n_sparse=90)
+    _compare(maps, dict(k=2.0, lambda1=0.5, lambda2=3.0, cg_tol=1e-5, tol=1e-3))
+    _compare(maps, dict(scale_filter=False, max_iter=2))
+    no_sparse = dict(maps, kps=np.zeros((0, 2), int), depth3d=np.zeros(0), zvars3d=np.zeros(0))
+    _compare(no_sparse)
+    dup = dict(maps, kps=np.concatenate([maps["kps"], maps["kps"][:20]]), depth3d=np.concatenate([maps["depth3d"], 1.02 * maps["depth3d"][:20]]),
+               zvars3d=np.concatenate([maps["zvars3d"], maps["zvars3d"][:20]]))
+    _compare(dup)  # duplicate pixels: NumPy's "last write wins" in A and b, every entry in the energy
+    with pytest.raises(capi.MpsfmHipError):
+        _hip(dict(maps, kps=np.array([[9999, 1]]), depth3d=np.ones(1), zvars3d=np.ones(1)))
+
+
+def test_cached_state_skips_unchanged_frame_like_the_reference():
+    maps = make_maps(36, 44, seed=6, n_sparse=70)
+    depth_g, s, wu, wv, state = _compare(maps)
+    maps2 = dict(maps, depth_init=depth_g)
+    d_o, changed_o, state2, info2 = _oracle(maps2, state)
+    d_g, s2, *_ = _hip(maps2, integrated=s["integrated"], energy_old=s["energy_old"], wu=wu, wv=wv)
+    assert changed_o is False and s2["changed"] is False and d_g is None
+    assert s2["energies"][0] == pytest.approx(info2["energies"][0], rel=1e-6)
+    # a changed sparse constraint set re-triggers the solve with the cached weights as the start
+    maps3 = dict(maps2, depth3d=maps["depth3d"] * 1.3)
+    d_o3, changed_o3, _, info3 = _oracle(maps3, state)
+    d_g3, s3, *_ = _hip(maps3, integrated=s["integrated"], energy_old=s["energy_old"], wu=wu, wv=wv)
+    assert s3["changed"] == changed_o3
+    np.testing.assert_allclose(s3["energies"], info3["energies"], rtol=1e-5)
+    if changed_o3:
+        np.testing.assert_allclose(d_g3, d_o3, rtol=5e-4)
+
+
+def test_reference_map_size_runs_fast():
+    """The reference normalises maps to ~387 px (290 x 387 = 112k unknowns)."""
+    maps = make_maps(290, 387, seed=8, n_sparse=1500)
+    depth, s, *_ = _hip(maps)
+    assert s["changed"] and np.isfinite(depth).all()
+    assert s["energy_final"] < 0.1 * s["energy_initial"]
+    e0 = np.median(np.abs(np.log(maps["depth_prior"] / maps["depth_true"])))
+    e1 = np.median(np.abs(np.log(depth / maps["depth_true"])))
+    assert e1 < e0
+    print("290x387: irls", s["irls_iterations"], "cg", s["cg_iters"], "device ms", s["ms"])
