@@ -121,11 +121,16 @@ def main():
     t_lin, t_den, t_upd = last["time_linearize_s"], last["time_dense_s"], last["time_update_s"]
     dominant = roof_dense if t_den > t_lin else roof_sweep
     other = roof_sweep if dominant is roof_dense else roof_dense
-    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(traffic_file):
+    # HBM bytes per launch of the track sweep from the committed PMC passes (profiles/rNN_pmc_traffic.json:
+    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE); null if absent
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if cands:
         try:
-            tr = json.load(open(traffic_file))
+            tr = json.load(open(cands[-1]))
             roof_sweep["traffic"] = tr.get("k_track_sweep_bytes_per_launch")
+            roof_sweep["traffic_source"] = os.path.basename(cands[-1])
         except Exception:  # noqa: BLE001
             pass
 

@@ -106,38 +106,50 @@ class Optimizer(BaseClass):
         image_ids = list(optim_ids)
         cam_of = {imid: i for i, imid in enumerate(image_ids)}
         in_config = set(image_ids)
-        point_ids, pt_of = [], {}
-        obs_cam, obs_pt, obs_xy = [], [], []
-        num_obs = {}
-
-        def pt_index(pid):
-            if pid not in pt_of:
-                pt_of[pid] = len(point_ids)
-                point_ids.append(pid)
-            return pt_of[pid]
-
+        # vectorised over each image's observations (no per-observation Python work)
+        cams_l, pids_l, xy_l = [], [], []
         for imid in image_ids:
             image = rec.images[imid]
             p2d = np.asarray(image.get_observation_point2D_idxs(), dtype=np.int64)
             if len(p2d) == 0:
                 continue
-            kps = np.asarray(image.keypoint_coordinates(p2d), dtype=np.float64)
-            for k, pid in enumerate(image.point3D_ids(p2d)):
-                obs_cam.append(cam_of[imid]); obs_pt.append(pt_index(pid)); obs_xy.append(kps[k])
-                num_obs[pid] = num_obs.get(pid, 0) + 1
+            cams_l.append(np.full(len(p2d), cam_of[imid], np.int32))
+            pids_l.append(np.asarray(image.point3D_ids(p2d), dtype=np.uint64))
+            xy_l.append(np.asarray(image.keypoint_coordinates(p2d), dtype=np.float64).reshape(-1, 2))
+        if pids_l:
+            uniq, inv, counts = np.unique(np.concatenate(pids_l), return_inverse=True, return_counts=True)
+            obs_cam, obs_pt, obs_xy = list(cams_l), [inv.astype(np.int32)], list(xy_l)
+            obs_cam = [np.concatenate(obs_cam)]
+        else:
+            uniq, counts = np.zeros(0, np.uint64), np.zeros(0, np.int64)
+            obs_cam, obs_pt, obs_xy = [], [], []
+        point_ids = [int(v) for v in uniq]
+        pt_of = dict(zip(point_ids, range(len(point_ids))))
+        num_obs = dict(zip(point_ids, (int(c) for c in counts)))
+        extra_cam, extra_pt, extra_xy = [], [], []
         for pid in variable_points:
             point = rec.points3D[pid]
             if num_obs.get(pid, 0) == point.track.length():
                 continue
+            if pid not in pt_of:
+                pt_of[pid] = len(point_ids)
+                point_ids.append(pid)
             for el in point.track.elements:
                 if el.image_id in in_config:
                     continue
                 if el.image_id not in cam_of:
                     cam_of[el.image_id] = len(image_ids)
                     image_ids.append(el.image_id)
-                xy = rec.images[el.image_id].points2D[el.point2D_idx].xy
-                obs_cam.append(cam_of[el.image_id]); obs_pt.append(pt_index(pid)); obs_xy.append(np.asarray(xy, np.float64))
+                extra_cam.append(cam_of[el.image_id]); extra_pt.append(pt_of[pid])
+                extra_xy.append(np.asarray(rec.images[el.image_id].points2D[el.point2D_idx].xy, np.float64))
                 num_obs[pid] = num_obs.get(pid, 0) + 1
+        if extra_cam:
+            obs_cam.append(np.array(extra_cam, np.int32)); obs_pt.append(np.array(extra_pt, np.int32))
+            obs_xy.append(np.array(extra_xy, np.float64).reshape(-1, 2))
+        obs_cam = np.concatenate(obs_cam) if obs_cam else np.zeros(0, np.int32)
+        obs_pt = np.concatenate(obs_pt) if obs_pt else np.zeros(0, np.int32)
+        obs_xy = np.concatenate(obs_xy) if obs_xy else np.zeros((0, 2))
+        self._sorted_point_ids = uniq  # bundle-image points, sorted: index = position (depth blocks look ids up here)
         n_cfg = len(optim_ids)
         pose_const = np.ones(len(image_ids), np.uint8)
         for ii in range(n_cfg):
@@ -188,7 +200,7 @@ class Optimizer(BaseClass):
                 div = depths / depth3d
                 mask = mask & (div < scale_filter_factor) & (div > (1 / scale_filter_factor))
             uu = image.depth.uncertainty_update
-            variances = np.array([uu[int(i)] for i in p2Ds], dtype=np.float64)
+            variances = np.asarray(uu, np.float64)[p2Ds] if isinstance(uu, np.ndarray) else np.array([uu[int(i)] for i in p2Ds], np.float64)
             if gross_outliers and image.depth.activated:
                 whitened = np.abs(np.log(depths).clip(1e-6, None) - np.log(depth3d).clip(1e-6, None)) / variances**0.5
                 mask = mask & (whitened < 3)
@@ -200,9 +212,8 @@ class Optimizer(BaseClass):
             m = param_multiplier * conf.rob_std
             params = m * variances**0.5 / depths
             magnitudes = depths**2 * inv_uncert
-            ci = cam_of[imid]
-            for k, pid in enumerate(p3Ds):
-                dobs_cam.append(ci); dobs_pt.append(pt_of[int(pid)])
+            dobs_cam.append(np.full(len(p3Ds), cam_of[imid], np.int32))
+            dobs_pt.append(np.searchsorted(self._sorted_point_ids, p3Ds).astype(np.int32))
             dobs_d.append(depths); dobs_m.append(magnitudes); dobs_a.append(params)
 
         n_cams = len(image_ids)
@@ -219,7 +230,8 @@ class Optimizer(BaseClass):
             obs_xy=np.array(obs_xy, np.float64).reshape(-1, 2), gauge_axis_cam=gauge if n_cams > 1 else -1,
             reproj_loss_type=_COLMAP_LOSS[str(conf.reproj_loss_name).upper()],
             reproj_loss_scale=conf.reproj_loss_scale * kp_std, reproj_loss_magnitude=1 / kp_std**2,
-            dobs_cam=np.array(dobs_cam, np.int32), dobs_pt=np.array(dobs_pt, np.int32),
+            dobs_cam=np.concatenate(dobs_cam) if dobs_cam else np.zeros(0, np.int32),
+            dobs_pt=np.concatenate(dobs_pt) if dobs_pt else np.zeros(0, np.int32),
             dobs_depth=np.concatenate(dobs_d) if dobs_d else np.zeros(0),
             dobs_magnitude=np.concatenate(dobs_m) if dobs_m else np.zeros(0),
             dobs_param=np.concatenate(dobs_a) if dobs_a else np.zeros(0),
@@ -346,7 +358,8 @@ class Optimizer(BaseClass):
             _, _, _, depth3d, _ = rec.project_image_3d_points(imid, p3Ds[mask])
             uu = image.depth.uncertainty_update
             D.append(depths[mask]); D3d.append(depth3d)
-            stds.append(np.array([uu[int(i)] for i in p2Ds[mask]]) ** 0.5)
+            vv = np.asarray(uu, np.float64)[p2Ds[mask]] if isinstance(uu, np.ndarray) else np.array([uu[int(i)] for i in p2Ds[mask]])
+            stds.append(vv**0.5)
         depths, depth3ds, dstds = np.concatenate(D), np.concatenate(D3d), np.concatenate(stds)
         log_stds = np.clip(dstds / depths, 1e-6, None)
         _, sigma = fit_robust_gaussian_mad((np.log(depths) - np.log(depth3ds)) / log_stds)
