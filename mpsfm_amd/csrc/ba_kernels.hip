@@ -145,8 +145,8 @@ enum { MODE_FULL = 0, MODE_DIAG = 1 };
 //   P4  flush the per-camera LDS accumulators, write the chunk partials
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
-  __shared__ double s_W[kObsMax * kWStride];
-  __shared__ double s_V[kPtsMax * 6];
+  __shared__ __attribute__((aligned(16))) double s_W[kObsMax * kWStride];
+  __shared__ __attribute__((aligned(16))) double s_V[kPtsMax * 6];
   __shared__ double s_g[kPtsMax * 3];
   __shared__ double s_U[kTileCams * 21];
   __shared__ double s_gc[kTileCams * 6];
@@ -322,12 +322,18 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
             if (e < e1) ent = ep[e];  // fetch the next pair while this one is processed
             const int ri = cur & 0xff, rj = (cur >> 8) & 0xff, lpt = (cur >> 16) & 0xff;
             const double* wi = &s_W[ri * kWStride + row * 3];
-            double Vi[6];
+            // 16-byte LDS reads: (V+D)^-1 (3 x b128) and W_j (9 x b128) are shared by the six lanes of the group
+            double Vi[6], wj[18];
+            {
+              const double2* v2 = reinterpret_cast<const double2*>(&s_V[lpt * 6]);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) Vi[k] = s_V[lpt * 6 + k];
+              for (int k = 0; k < 3; ++k) { const double2 t = v2[k]; Vi[2 * k] = t.x; Vi[2 * k + 1] = t.y; }
+              const double2* w2 = reinterpret_cast<const double2*>(&s_W[rj * kWStride]);
+#pragma unroll
+              for (int k = 0; k < 9; ++k) { const double2 t = w2[k]; wj[2 * k] = t.x; wj[2 * k + 1] = t.y; }
+            }
             double y[3];
             sym3_mul(Vi, wi[0], wi[1], wi[2], y);
-            const double* wj = &s_W[rj * kWStride];
 #pragma unroll
             for (int bb = 0; bb < 6; ++bb) acc[bb] += y[0] * wj[bb * 3] + y[1] * wj[bb * 3 + 1] + y[2] * wj[bb * 3 + 2];
           }

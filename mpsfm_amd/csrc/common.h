@@ -33,7 +33,7 @@ constexpr int kLocalCamsMax = 64;  // local camera list length (beyond kTileCams
 constexpr int kPairGroup = 6;   // lanes cooperating on one 6x6 block of the reduced system (one row each)
 constexpr int kItemPairs = MPSFM_ITEM_PAIRS;  // pairs per Schur work item (heavier blocks are split for balance)
 constexpr int kEntStage = MPSFM_ENT_STAGE; // pair entries of a chunk staged in LDS (larger chunks read them from HBM)
-constexpr int kWStride = 19;    // padded row stride (doubles) of the per-record W block in LDS
+constexpr int kWStride = 18;    // row stride (doubles) of the per-record W block in LDS: 144 B, keeps rows 16-B aligned for ds_read_b128
 constexpr int kCamRec = 24;     // doubles per camera table record
 
 // camera table record: R[9] t[3] K[4] cs[6] pad[2]
