@@ -303,6 +303,11 @@ struct IntPool {
   }
 };
 
+struct StreamGuard {
+  hipStream_t st = nullptr;
+  ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
+};
+
 }  // namespace mpsfm
 
 using namespace mpsfm;
@@ -320,6 +325,10 @@ extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device,
   if (device < 0 || device >= ndev) return ifail(MPSFM_EINVAL, "device ordinal out of range");
   INT_TRY(hipSetDevice(device));
   std::memset(S, 0, sizeof(*S));
+  // a stream of its own: concurrent calls from different host threads (one image each) overlap on the GPU
+  StreamGuard sg;
+  INT_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+  hipStream_t st = sg.st;
   const int H = P->H, W = P->W, N = H * W;
   for (int i = 0; i < P->n_sparse; ++i)
     if (P->sparse_x[i] < 0 || P->sparse_x[i] >= W || P->sparse_y[i] < 0 || P->sparse_y[i] >= H)
@@ -362,55 +371,55 @@ extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device,
   }
   double* in_prior = d_in; double* in_unc = d_in + N; double* in_init = d_in + 2 * (size_t)N; double* in_nrm = d_in + 3 * (size_t)N;
   double* in_nvar = d_in + 6 * (size_t)N;
-  INT_TRY(hipMemcpy(in_prior, P->depth_prior, sizeof(double) * N, hipMemcpyHostToDevice));
-  INT_TRY(hipMemcpy(in_unc, P->depth_uncertainty, sizeof(double) * N, hipMemcpyHostToDevice));
-  INT_TRY(hipMemcpy(in_init, P->depth_init, sizeof(double) * N, hipMemcpyHostToDevice));
-  INT_TRY(hipMemcpy(in_nrm, P->normals, sizeof(double) * 3 * N, hipMemcpyHostToDevice));
-  INT_TRY(hipMemcpy(in_nvar, P->normals_var, sizeof(double) * 3 * N, hipMemcpyHostToDevice));
-  INT_TRY(hipMemcpy(d_valid, P->valid, (size_t)N, hipMemcpyHostToDevice));
-  INT_TRY(hipMemcpy(D.spd, spd.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-  INT_TRY(hipMemcpy(D.spb, spb.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-  INT_TRY(hipMemset(D.p0, 0, sizeof(double) * 2 * (size_t)N));
+  INT_TRY(hipMemcpyAsync(in_prior, P->depth_prior, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(in_unc, P->depth_uncertainty, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(in_init, P->depth_init, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(in_nrm, P->normals, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(in_nvar, P->normals_var, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(d_valid, P->valid, (size_t)N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(D.spd, spd.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(D.spb, spb.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemsetAsync(D.p0, 0, sizeof(double) * 2 * (size_t)N, st));
   if (!ids.empty()) {
-    INT_TRY(hipMemcpy(d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
-    INT_TRY(hipMemcpy(d_sp, sprec.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice));
-    INT_TRY(hipMemcpy(d_sp + ids.size(), sdep.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice));
+    INT_TRY(hipMemcpyAsync(d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(d_sp, sprec.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(d_sp + ids.size(), sdep.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
   }
   const bool keep_w = P->init && P->integrated && P->wu && P->wv;
   if (keep_w) {
-    INT_TRY(hipMemcpy(D.wu, P->wu, sizeof(double) * N, hipMemcpyHostToDevice));
-    INT_TRY(hipMemcpy(D.wv, P->wv, sizeof(double) * N, hipMemcpyHostToDevice));
+    INT_TRY(hipMemcpyAsync(D.wu, P->wu, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(D.wv, P->wv, sizeof(double) * N, hipMemcpyHostToDevice, st));
   }
   hipEvent_t e0, e1;
   INT_TRY(hipEventCreate(&e0)); INT_TRY(hipEventCreate(&e1));
-  INT_TRY(hipEventRecord(e0, 0));
+  INT_TRY(hipEventRecord(e0, st));
   PrepArgs pa{H, W, in_prior, in_unc, in_nrm, in_nvar, in_init, d_valid, P->K[0], P->K[1], P->K[2], P->K[3], P->large_number,
               P->depth_magnitude_multiplier, P->normals_magnitude_multiplier};
-  hipLaunchKernelGGL(k_int_prepare, dim3(G), dim3(kIT), 0, 0, pa, D);
+  hipLaunchKernelGGL(k_int_prepare, dim3(G), dim3(kIT), 0, st, pa, D);
 
   std::vector<double> hpart((size_t)G * 8);
   auto energy = [&](int keep, double* out) -> int {
-    hipLaunchKernelGGL(k_int_weights, dim3(G), dim3(kIT), 0, 0, D, P->k, P->lambda1, keep);
-    hipLaunchKernelGGL(k_int_sparse_energy, dim3(1), dim3(kIT), 0, 0, (int)ids.size(), d_ids, d_sp, d_sp + ids.size(), D.z, P->lambda2,
+    hipLaunchKernelGGL(k_int_weights, dim3(G), dim3(kIT), 0, st, D, P->k, P->lambda1, keep);
+    hipLaunchKernelGGL(k_int_sparse_energy, dim3(1), dim3(kIT), 0, st, (int)ids.size(), d_ids, d_sp, d_sp + ids.size(), D.z, P->lambda2,
                        D.state + 7);
-    INT_TRY(hipMemcpy(hpart.data(), D.part, sizeof(double) * hpart.size(), hipMemcpyDeviceToHost));
-    double st;
-    INT_TRY(hipMemcpy(&st, D.state + 7, sizeof(double), hipMemcpyDeviceToHost));
+    INT_TRY(hipMemcpyAsync(hpart.data(), D.part, sizeof(double) * hpart.size(), hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
+    double e_sparse;
+    INT_TRY(hipMemcpyAsync(&e_sparse, D.state + 7, sizeof(double), hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
     double e_n = 0.0, e_d = 0.0;
     for (int i = 0; i < G; ++i) { e_n += hpart[(size_t)i * 8]; e_d += hpart[(size_t)i * 8 + 1]; }
-    *out = e_n + e_d + (ids.empty() ? 0.0 : st);
+    *out = e_n + e_d + (ids.empty() ? 0.0 : e_sparse);
     return 0;
   };
   auto finish = [&](int rc) {
     float ms = 0.f;
-    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
     S->ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
   };
   auto save_weights = [&]() -> int {
-    if (P->wu) INT_TRY(hipMemcpy(P->wu, D.wu, sizeof(double) * N, hipMemcpyDeviceToHost));
-    if (P->wv) INT_TRY(hipMemcpy(P->wv, D.wv, sizeof(double) * N, hipMemcpyDeviceToHost));
+    if (P->wu) INT_TRY(hipMemcpyAsync(P->wu, D.wu, sizeof(double) * N, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
+    if (P->wv) INT_TRY(hipMemcpyAsync(P->wv, D.wv, sizeof(double) * N, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
     return 0;
   };
 
@@ -428,22 +437,22 @@ extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device,
   double min_energy = en;
   bool success = true;
   for (int it = 0; it < P->max_iter; ++it) {
-    hipLaunchKernelGGL(k_int_system, dim3(G), dim3(kIT), 0, 0, D, P->lambda1);
+    hipLaunchKernelGGL(k_int_system, dim3(G), dim3(kIT), 0, st, D, P->lambda1);
     // preconditioned CG, scipy.sparse.linalg.cg semantics (x0 = z, M = 1/clip(diag), rtol)
-    INT_TRY(hipMemsetAsync(D.state, 0, sizeof(double) * 7, 0));
-    hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(kIT), 0, 0, D);
+    INT_TRY(hipMemsetAsync(D.state, 0, sizeof(double) * 7, st));
+    hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(kIT), 0, st, D);
     int k = 0, cg_its = 0;
     bool done = false;
     while (!done && k < P->cg_max_iter) {
       const int batch = std::min(16, P->cg_max_iter - k);
       for (int j = 0; j < batch; ++j, ++k) {
-        hipLaunchKernelGGL(k_cg_dir, dim3(G), dim3(kIT), 0, 0, D, G, k, k == 0 ? 1 : 0, P->cg_tol);
-        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(kIT), 0, 0, D, G, k);
+        hipLaunchKernelGGL(k_cg_dir, dim3(G), dim3(kIT), 0, st, D, G, k, k == 0 ? 1 : 0, P->cg_tol);
+        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(kIT), 0, st, D, G, k);
       }
-      double st[8];
-      INT_TRY(hipMemcpy(st, D.state, sizeof(st), hipMemcpyDeviceToHost));
-      done = st[2] != 0.0;
-      cg_its = (int)st[3];
+      double hs[8];
+      INT_TRY(hipMemcpyAsync(hs, D.state, sizeof(hs), hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
+      done = hs[2] != 0.0;
+      cg_its = (int)hs[3];
     }
     INT_TRY(hipGetLastError());
     S->cg_iters[it] = cg_its;
@@ -466,7 +475,7 @@ extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device,
   }
   S->energy_old_out = en;
   S->changed = 1;
-  hipLaunchKernelGGL(k_int_exp, dim3(G), dim3(kIT), 0, 0, N, D.z, d_out);
-  INT_TRY(hipMemcpy(depth_out, d_out, sizeof(double) * N, hipMemcpyDeviceToHost));
+  hipLaunchKernelGGL(k_int_exp, dim3(G), dim3(kIT), 0, st, N, D.z, d_out);
+  INT_TRY(hipMemcpyAsync(depth_out, d_out, sizeof(double) * N, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
   return finish(0);
 }

@@ -73,3 +73,17 @@ class Integration:
         self.count_skipped += 1
         self.depth.data = depth
         return True
+
+
+def integrate_bundle(images, workers: int = 8, cache_device="cpu"):
+    """Integrate several images concurrently (what MpsfmMapper.integrate_bundle loops over, reference
+    mpsfm/sfm/mapper/base.py:619-631).  Every call of mpsfm_integrate_depth runs on a HIP stream of its
+    own and ctypes releases the GIL, so the per-image launch sequences overlap on the GPU; results are
+    identical to integrating one image after the other.  Returns the per-image `changed` flags."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    images = list(images)
+    if workers <= 1 or len(images) <= 1:
+        return [im.integrate(cache_device=cache_device) for im in images]
+    with ThreadPoolExecutor(max_workers=min(workers, len(images))) as ex:
+        return list(ex.map(lambda im: im.integrate(cache_device=cache_device), images))

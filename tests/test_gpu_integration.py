@@ -140,3 +140,23 @@ def test_integration_mixin_on_a_scene_matches_oracle():
         np.testing.assert_allclose(img.depth.data, d_o, rtol=5e-4)
         assert np.any(img.depth.data != before)
         assert img.integrate() is False  # nothing changed since: skipped like the reference does
+
+
+def test_concurrent_integration_is_identical_and_faster():
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    cases = [make_maps(145, 193, seed=100 + i, n_sparse=400) for i in range(12)]
+    _hip(cases[0])  # warm up
+    t0 = time.perf_counter()
+    seq = [_hip(m) for m in cases]
+    t_seq = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        par = list(ex.map(_hip, cases))
+    t_par = time.perf_counter() - t0
+    for (d1, s1, *_), (d2, s2, *_) in zip(seq, par):
+        assert s1["cg_iters"] == s2["cg_iters"]
+        np.testing.assert_array_equal(d1, d2)
+    print(f"12 images 145x193: sequential {1e3 * t_seq:.1f} ms, 6 threads {1e3 * t_par:.1f} ms")
+    assert t_par < t_seq
