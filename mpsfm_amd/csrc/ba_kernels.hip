@@ -212,12 +212,14 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       }
       if (lcam != (int)kLcamConst && !(A.dbg & 1)) {
         const int slot = s_slot[lcam];
-        // diag(U)
+        // diag(U): in the full sweep the LDS copy comes for free from the diagonal of the U tile (P4)
+        if (MODE == MODE_DIAG || lcam >= kTileCams) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const double du = L.Jc[i] * L.Jc[i] + L.Jc[6 + i] * L.Jc[6 + i] + L.Jc[12 + i] * L.Jc[12 + i];
-          if (lcam < kTileCams) atomicAdd(&s_du[lcam * 6 + i], du);
-          else atomicAdd(&A.diagU[(size_t)slot * 6 + i], du);
+          for (int i = 0; i < 6; ++i) {
+            const double du = L.Jc[i] * L.Jc[i] + L.Jc[6 + i] * L.Jc[6 + i] + L.Jc[12 + i] * L.Jc[12 + i];
+            if (lcam < kTileCams) atomicAdd(&s_du[lcam * 6 + i], du);
+            else atomicAdd(&A.diagU[(size_t)slot * 6 + i], du);
+          }
         }
         if (MODE == MODE_FULL) {
           // g_c and the upper triangle of U_c (21 values, packed row-major a <= b)
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
         int u = idx - lc * 21, i = 0;
         while (u >= 6 - i) { u -= 6 - i; ++i; }  // packed (i, j >= i) -> i, j = i + u
         atomicAdd(&A.Sblk[ut_block(s_slot[lc], s_slot[lc], A.ncv) * 36 + i * 6 + i + u], v);
+        if (u == 0) atomicAdd(&A.diagU[(size_t)s_slot[lc] * 6 + i], v);  // diagonal entry of U
       }
     }
   }
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     const int lc = tid / 6;
     if (lc < ncam) {
       const size_t o = (size_t)s_slot[lc] * 6 + (tid - lc * 6);
-      if (s_du[tid] != 0.0) atomicAdd(&A.diagU[o], s_du[tid]);
+      if (MODE == MODE_DIAG && s_du[tid] != 0.0) atomicAdd(&A.diagU[o], s_du[tid]);
       if (MODE == MODE_FULL) {
         if (s_gc[tid] != 0.0) atomicAdd(&A.gc[o], s_gc[tid]);
         if (s_wv[tid] != 0.0) atomicAdd(&A.wv[o], s_wv[tid]);
