@@ -270,6 +270,20 @@ typedef struct mpsfm_int_summary {
 int mpsfm_integrate_depth(const mpsfm_int_problem* problem, int32_t device, double* depth_out /* [H*W] */,
                           mpsfm_int_summary* summary);
 
+/* ---- row f4: uncertainty propagation through the integration (reference
+ *    mpsfm/sfm/scene/image/integration.py:51-79 `IntegrationUncertainty`, :522-574 `calculate_hessian`,
+ *    :576-616 `calculate_int_covs_at_points / _at_kps`).  The "Hessian" is the matrix of calc_Amat built at
+ *    the depth checkpoint `depth_init` with weights recomputed from it (init=False) and, when use_sparse==0
+ *    (conf.ignore_depths, the default), without the sparse-point term; no scale filter.  The reference solves
+ *    H x = e_k per query pixel with cholespy (float32) and returns x.sum(0): the column sum of H^-1, which by
+ *    symmetry is (H^-1 1)[k] — computed here by ONE preconditioned-CG solve in float64 to `rtol`.
+ *    var_out[i] = value at pixel (qx[i], qy[i]); field_out (may be NULL) receives the whole H*W field.
+ *    summary: cg_iters[0] iterations, changed = 1 when the tolerance was met, ms = device time. ---- */
+int mpsfm_integration_variances(const mpsfm_int_problem* problem, int32_t device, int32_t use_sparse, int32_t n_query,
+                                const int32_t* qx, const int32_t* qy, double rtol, int32_t max_iter,
+                                double* var_out /* [n_query] */, double* field_out /* [H*W] or NULL */,
+                                mpsfm_int_summary* summary);
+
 #ifdef __cplusplus
 }
 #endif

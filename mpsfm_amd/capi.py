@@ -22,7 +22,7 @@ EXPORTS = [
     "mpsfm_ba_solve_resident", "mpsfm_ba_get_state", "mpsfm_ba_destroy", "mpsfm_ba_eval_cost",
     "mpsfm_ba_sweep_once", "mpsfm_ba_get_reduced_system", "mpsfm_ba_reduced_dim",
     "mpsfm_ba_get_dense_solution", "mpsfm_ba_dense_solve_once", "mpsfm_point_covs",
-    "mpsfm_triangulate_tracks", "mpsfm_filter_tracks", "mpsfm_integrate_depth",
+    "mpsfm_triangulate_tracks", "mpsfm_filter_tracks", "mpsfm_integrate_depth", "mpsfm_integration_variances",
 ]
 
 _lib = None
@@ -215,10 +215,10 @@ INT_DEFAULT_CONF = dict(
 )
 
 
-def integrate_depth(depth_prior, depth_uncertainty, valid, normals, normals_var, depth_init, K, kps, depth3d, zvars3d,
-                    conf=None, init=True, integrated=False, energy_old=0.0, wu=None, wv=None, device=0):
-    """mpsfm_integrate_depth.  Returns (depth map or None, summary dict, wu, wv)."""
-    from .problem import CIntProblem, CIntSummary
+def _int_problem(depth_prior, depth_uncertainty, valid, normals, normals_var, depth_init, K, kps, depth3d, zvars3d, conf,
+                 init=True, integrated=False, energy_old=0.0, wu=None, wv=None):
+    """Fills a CIntProblem; returns (P, keepalive tuple, (H, W), wu, wv)."""
+    from .problem import CIntProblem
 
     c = dict(INT_DEFAULT_CONF)
     c.update(conf or {})
@@ -246,6 +246,17 @@ def integrate_depth(depth_prior, depth_uncertainty, valid, normals, normals_var,
     P.max_iter, P.cg_max_iter, P.scale_filter = int(c["max_iter"]), int(c["cg_max_iter"]), int(bool(c["scale_filter"]))
     P.init, P.integrated, P.energy_old = int(bool(init)), int(bool(integrated)), float(energy_old or 0.0)
     P.wu, P.wv = wu.ctypes.data, wv.ctypes.data
+    keep = (depth_prior, depth_uncertainty, depth_init, valid, normals, normals_var, sx, sy, depth3d, zvars3d)
+    return P, keep, (H, W), wu, wv
+
+
+def integrate_depth(depth_prior, depth_uncertainty, valid, normals, normals_var, depth_init, K, kps, depth3d, zvars3d,
+                    conf=None, init=True, integrated=False, energy_old=0.0, wu=None, wv=None, device=0):
+    """mpsfm_integrate_depth.  Returns (depth map or None, summary dict, wu, wv)."""
+    from .problem import CIntSummary
+
+    P, _keep, (H, W), wu, wv = _int_problem(depth_prior, depth_uncertainty, valid, normals, normals_var, depth_init, K, kps,
+                                            depth3d, zvars3d, conf, init, integrated, energy_old, wu, wv)
     out = np.zeros((H, W))
     S = CIntSummary()
     L = lib()
@@ -257,3 +268,30 @@ def integrate_depth(depth_prior, depth_uncertainty, valid, normals, normals_var,
                    energy_final=S.energy_final, cg_iters=[S.cg_iters[i] for i in range(n)],
                    energies=[S.energies[i] for i in range(n + 1)], ms=S.ms)
     return (out if S.changed else None), summary, wu, wv
+
+
+def integration_variances(depth_prior, depth_uncertainty, valid, normals, normals_var, depth_checkpoint, K, query_xy,
+                          kps=None, depth3d=None, zvars3d=None, use_sparse=False, conf=None, rtol=1e-10, max_iter=50000,
+                          device=0, return_field=False):
+    """mpsfm_integration_variances: var(log depth) propagated through the integration at integer pixels
+    `query_xy` [n,2] (x, y).  Returns (variances [n], summary dict[, field [H,W]])."""
+    from .problem import CIntSummary
+
+    empty = np.zeros((0, 2), np.int64)
+    P, _keep, (H, W), _, _ = _int_problem(depth_prior, depth_uncertainty, valid, normals, normals_var, depth_checkpoint, K,
+                                          empty if kps is None else kps, [] if depth3d is None else depth3d,
+                                          [] if zvars3d is None else zvars3d, conf, init=False)
+    q = np.ascontiguousarray(query_xy, np.int64).reshape(-1, 2)
+    qx, qy = np.ascontiguousarray(q[:, 0], np.int32), np.ascontiguousarray(q[:, 1], np.int32)
+    out = np.zeros(len(q))
+    field = np.zeros((H, W)) if return_field else None
+    S = CIntSummary()
+    L = lib()
+    L.mpsfm_integration_variances.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.mpsfm_integration_variances(C.byref(P), device, int(bool(use_sparse)), len(q), qx.ctypes.data if len(q) else None,
+                                         qy.ctypes.data if len(q) else None, float(rtol), int(max_iter),
+                                         out.ctypes.data if len(q) else None, field.ctypes.data if return_field else None,
+                                         C.byref(S)))
+    summary = dict(converged=bool(S.changed), cg_iterations=S.cg_iterations_total, ms=S.ms)
+    return (out, summary, field) if return_field else (out, summary)

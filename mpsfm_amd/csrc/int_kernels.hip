@@ -308,60 +308,69 @@ struct StreamGuard {
   ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
 };
 
-}  // namespace mpsfm
+// b = 1, x0 = 0: the system of IntegrationUncertainty (column sums of the inverse)
+__global__ __launch_bounds__(kIT) void k_int_unit_rhs(IntDev D) {
+  const int p = blockIdx.x * kIT + threadIdx.x;
+  if (p < D.N) { D.b[p] = 1.0; D.z[p] = 0.0; }
+}
 
-using namespace mpsfm;
+// Host-side preparation shared by the two entry points: process_sparse_depth (+ the scale filter of
+// _integrate when asked), device buffers, uploads.
+struct IntSetup {
+  IntPool pool;
+  IntDev D{};
+  int G = 0;
+  std::vector<int32_t> ids;
+  std::vector<double> sprec, sdep;
+  int32_t* d_ids = nullptr;
+  double *d_sp = nullptr, *d_out = nullptr, *d_in = nullptr;
+  uint8_t* d_valid = nullptr;
+};
 
-extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device, double* depth_out, mpsfm_int_summary* S) {
-  if (!P || !depth_out || !S) return ifail(MPSFM_EINVAL, "NULL argument");
+static int int_check(const mpsfm_int_problem* P, int32_t device) {
   if (P->H < 2 || P->W < 2) return ifail(MPSFM_EINVAL, "map must be at least 2x2");
   if (!P->depth_prior || !P->depth_uncertainty || !P->valid || !P->normals || !P->normals_var || !P->depth_init)
     return ifail(MPSFM_EINVAL, "map pointers are NULL");
   if (P->n_sparse < 0 || (P->n_sparse > 0 && (!P->sparse_x || !P->sparse_y || !P->sparse_depth3d || !P->sparse_zvar)))
     return ifail(MPSFM_EINVAL, "sparse arrays are NULL");
-  if (P->max_iter < 0 || P->max_iter > MPSFM_INT_MAX_IRLS) return ifail(MPSFM_EINVAL, "max_iter out of range");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ifail(MPSFM_ENODEVICE, "no HIP device visible: libmpsfm_hip has no CPU fallback");
   if (device < 0 || device >= ndev) return ifail(MPSFM_EINVAL, "device ordinal out of range");
-  INT_TRY(hipSetDevice(device));
-  std::memset(S, 0, sizeof(*S));
-  // a stream of its own: concurrent calls from different host threads (one image each) overlap on the GPU
-  StreamGuard sg;
-  INT_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
-  hipStream_t st = sg.st;
-  const int H = P->H, W = P->W, N = H * W;
   for (int i = 0; i < P->n_sparse; ++i)
-    if (P->sparse_x[i] < 0 || P->sparse_x[i] >= W || P->sparse_y[i] < 0 || P->sparse_y[i] >= H)
+    if (P->sparse_x[i] < 0 || P->sparse_x[i] >= P->W || P->sparse_y[i] < 0 || P->sparse_y[i] >= P->H)
       return ifail(MPSFM_EINVAL, "sparse pixel outside the map");
+  return 0;
+}
 
-  // ---- host: process_sparse_depth + scale filter (:285-293, :392-398); NumPy "last write wins" for A and b
-  std::vector<int32_t> ids; std::vector<double> sprec, sdep;
+static int int_setup(const mpsfm_int_problem* P, bool use_sparse, bool scale_filter, hipStream_t st, IntSetup& U) {
+  const int H = P->H, W = P->W, N = H * W;
+  // NumPy "last write wins" for duplicate pixels in A and b
   std::vector<double> spd((size_t)N, 0.0), spb((size_t)N, 0.0);
-  for (int i = 0; i < P->n_sparse; ++i) {
+  for (int i = 0; use_sparse && i < P->n_sparse; ++i) {
     const int id = P->sparse_y[i] * W + P->sparse_x[i];
     const double d3 = P->sparse_depth3d[i];
-    if (P->scale_filter) {
+    if (scale_filter) {
       const double div = std::exp(std::log(d3)) / std::exp(std::log(P->depth_prior[id]));
       if (!(div < P->scale_filter_factor && div > 1.0 / P->scale_filter_factor)) continue;
     }
-    ids.push_back(id); sprec.push_back((1.0 / P->sparse_zvar[i]) * d3 * d3); sdep.push_back(std::log(d3));
+    U.ids.push_back(id); U.sprec.push_back((1.0 / P->sparse_zvar[i]) * d3 * d3); U.sdep.push_back(std::log(d3));
   }
-  for (size_t i = 0; i < ids.size(); ++i) { spd[ids[i]] = P->lambda2 * sprec[i]; spb[ids[i]] = P->lambda2 * sprec[i] * sdep[i]; }
+  const auto& ids = U.ids;
+  for (size_t i = 0; i < ids.size(); ++i) { spd[ids[i]] = P->lambda2 * U.sprec[i]; spb[ids[i]] = P->lambda2 * U.sprec[i] * U.sdep[i]; }
 
-  // ---- device buffers
-  IntPool pool;
-  const int G = (N + kIT - 1) / kIT;
-  IntDev D{};
+  IntPool& pool = U.pool;
+  IntDev& D = U.D;
+  const int G = U.G = (N + kIT - 1) / kIT;
   D.H = H; D.W = W; D.N = N;
   double* big = pool.get<double>((size_t)N * 28);
-  double* d_in = pool.get<double>((size_t)N * 9);
-  uint8_t* d_valid = pool.get<uint8_t>((size_t)N);
+  double* d_in = U.d_in = pool.get<double>((size_t)N * 9);
+  U.d_valid = pool.get<uint8_t>((size_t)N);
   D.part = pool.get<double>((size_t)G * 8);
   D.state = pool.get<double>(8);
-  int32_t* d_ids = pool.get<int32_t>(ids.size());
-  double* d_sp = pool.get<double>(ids.size() * 2 + 1);
-  double* d_out = pool.get<double>((size_t)N);
-  if (!big || !d_in || !d_valid || !D.part || !D.state || !d_ids || !d_sp || !d_out) return ifail(MPSFM_ENOMEM, "hipMalloc failed");
+  U.d_ids = pool.get<int32_t>(ids.size());
+  U.d_sp = pool.get<double>(ids.size() * 2 + 1);
+  U.d_out = pool.get<double>((size_t)N);
+  if (!big || !d_in || !U.d_valid || !D.part || !D.state || !U.d_ids || !U.d_sp || !U.d_out) return ifail(MPSFM_ENOMEM, "hipMalloc failed");
   {
     double* c = big;
     auto take = [&](size_t k) { double* r = c; c += k * (size_t)N; return r; };
@@ -369,22 +378,79 @@ extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device,
     D.wu = take(1); D.wv = take(1); D.w4 = take(4); D.d = take(1); D.cr = take(1); D.cd = take(1); D.b = take(1); D.minv = take(1);
     D.spd = take(1); D.spb = take(1); D.r = take(1); D.zz = take(1); D.p0 = take(1); D.p1 = take(1); D.q = take(1);
   }
-  double* in_prior = d_in; double* in_unc = d_in + N; double* in_init = d_in + 2 * (size_t)N; double* in_nrm = d_in + 3 * (size_t)N;
-  double* in_nvar = d_in + 6 * (size_t)N;
-  INT_TRY(hipMemcpyAsync(in_prior, P->depth_prior, sizeof(double) * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(in_unc, P->depth_uncertainty, sizeof(double) * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(in_init, P->depth_init, sizeof(double) * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(in_nrm, P->normals, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(in_nvar, P->normals_var, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(d_valid, P->valid, (size_t)N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(d_in, P->depth_prior, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(d_in + N, P->depth_uncertainty, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(d_in + 2 * (size_t)N, P->depth_init, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(d_in + 3 * (size_t)N, P->normals, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(d_in + 6 * (size_t)N, P->normals_var, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(U.d_valid, P->valid, (size_t)N, hipMemcpyHostToDevice, st));
   INT_TRY(hipMemcpyAsync(D.spd, spd.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
   INT_TRY(hipMemcpyAsync(D.spb, spb.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
   INT_TRY(hipMemsetAsync(D.p0, 0, sizeof(double) * 2 * (size_t)N, st));
   if (!ids.empty()) {
-    INT_TRY(hipMemcpyAsync(d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(d_sp, sprec.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(d_sp + ids.size(), sdep.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(U.d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(U.d_sp, U.sprec.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(U.d_sp + ids.size(), U.sdep.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
   }
+  // spd / spb are host vectors that die with this frame: the copies above must have left them
+  INT_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+static void int_launch_prepare(const mpsfm_int_problem* P, IntSetup& U, hipStream_t st) {
+  const size_t N = (size_t)U.D.N;
+  PrepArgs pa{P->H, P->W, U.d_in, U.d_in + N, U.d_in + 3 * N, U.d_in + 6 * N, U.d_in + 2 * N, U.d_valid,
+              P->K[0], P->K[1], P->K[2], P->K[3], P->large_number, P->depth_magnitude_multiplier, P->normals_magnitude_multiplier};
+  hipLaunchKernelGGL(k_int_prepare, dim3(U.G), dim3(kIT), 0, st, pa, U.D);
+}
+
+// preconditioned CG with scipy.sparse.linalg.cg semantics (x0 = D.z, M = 1/clip(diag), rtol); the
+// host looks at the done flag every 16 iterations
+static int int_run_cg(IntDev& D, int G, hipStream_t st, double rtol, int max_iter, int* its, bool* converged) {
+  INT_TRY(hipMemsetAsync(D.state, 0, sizeof(double) * 7, st));
+  hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(kIT), 0, st, D);
+  int k = 0;
+  bool done = false;
+  *its = 0;
+  while (!done && k < max_iter) {
+    const int batch = std::min(16, max_iter - k);
+    for (int j = 0; j < batch; ++j, ++k) {
+      hipLaunchKernelGGL(k_cg_dir, dim3(G), dim3(kIT), 0, st, D, G, k, k == 0 ? 1 : 0, rtol);
+      hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(kIT), 0, st, D, G, k);
+    }
+    double hs[8];
+    INT_TRY(hipMemcpyAsync(hs, D.state, sizeof(hs), hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
+    done = hs[2] != 0.0;
+    *its = (int)hs[3];
+  }
+  INT_TRY(hipGetLastError());
+  if (converged) *converged = done;
+  return 0;
+}
+
+}  // namespace mpsfm
+
+using namespace mpsfm;
+
+extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device, double* depth_out, mpsfm_int_summary* S) {
+  if (!P || !depth_out || !S) return ifail(MPSFM_EINVAL, "NULL argument");
+  if (P->max_iter < 0 || P->max_iter > MPSFM_INT_MAX_IRLS) return ifail(MPSFM_EINVAL, "max_iter out of range");
+  if (int rc = int_check(P, device)) return rc;
+  INT_TRY(hipSetDevice(device));
+  std::memset(S, 0, sizeof(*S));
+  // a stream of its own: concurrent calls from different host threads (one image each) overlap on the GPU
+  StreamGuard sg;
+  INT_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+  hipStream_t st = sg.st;
+  const int N = P->H * P->W;
+  IntSetup U;
+  if (int rc = int_setup(P, true, P->scale_filter != 0, st, U)) return rc;
+  IntDev& D = U.D;
+  const int G = U.G;
+  const auto& ids = U.ids;
+  int32_t* d_ids = U.d_ids;
+  double* d_sp = U.d_sp;
+  double* d_out = U.d_out;
   const bool keep_w = P->init && P->integrated && P->wu && P->wv;
   if (keep_w) {
     INT_TRY(hipMemcpyAsync(D.wu, P->wu, sizeof(double) * N, hipMemcpyHostToDevice, st));
@@ -393,9 +459,7 @@ extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device,
   hipEvent_t e0, e1;
   INT_TRY(hipEventCreate(&e0)); INT_TRY(hipEventCreate(&e1));
   INT_TRY(hipEventRecord(e0, st));
-  PrepArgs pa{H, W, in_prior, in_unc, in_nrm, in_nvar, in_init, d_valid, P->K[0], P->K[1], P->K[2], P->K[3], P->large_number,
-              P->depth_magnitude_multiplier, P->normals_magnitude_multiplier};
-  hipLaunchKernelGGL(k_int_prepare, dim3(G), dim3(kIT), 0, st, pa, D);
+  int_launch_prepare(P, U, st);
 
   std::vector<double> hpart((size_t)G * 8);
   auto energy = [&](int keep, double* out) -> int {
@@ -438,23 +502,8 @@ extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device,
   bool success = true;
   for (int it = 0; it < P->max_iter; ++it) {
     hipLaunchKernelGGL(k_int_system, dim3(G), dim3(kIT), 0, st, D, P->lambda1);
-    // preconditioned CG, scipy.sparse.linalg.cg semantics (x0 = z, M = 1/clip(diag), rtol)
-    INT_TRY(hipMemsetAsync(D.state, 0, sizeof(double) * 7, st));
-    hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(kIT), 0, st, D);
-    int k = 0, cg_its = 0;
-    bool done = false;
-    while (!done && k < P->cg_max_iter) {
-      const int batch = std::min(16, P->cg_max_iter - k);
-      for (int j = 0; j < batch; ++j, ++k) {
-        hipLaunchKernelGGL(k_cg_dir, dim3(G), dim3(kIT), 0, st, D, G, k, k == 0 ? 1 : 0, P->cg_tol);
-        hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(kIT), 0, st, D, G, k);
-      }
-      double hs[8];
-      INT_TRY(hipMemcpyAsync(hs, D.state, sizeof(hs), hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
-      done = hs[2] != 0.0;
-      cg_its = (int)hs[3];
-    }
-    INT_TRY(hipGetLastError());
+    int cg_its = 0;
+    if (int rc = int_run_cg(D, G, st, P->cg_tol, P->cg_max_iter, &cg_its, nullptr)) return finish(rc);
     S->cg_iters[it] = cg_its;
     S->cg_iterations_total += cg_its;
     const double energy_old = en;
@@ -478,4 +527,53 @@ extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device,
   hipLaunchKernelGGL(k_int_exp, dim3(G), dim3(kIT), 0, st, N, D.z, d_out);
   INT_TRY(hipMemcpyAsync(depth_out, d_out, sizeof(double) * N, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
   return finish(0);
+}
+
+// IntegrationUncertainty.solve (reference integration.py:51-79) on the matrix of calculate_hessian
+// (:522-574).  The reference solves H x = e_k for every query pixel k and returns x.sum(0) (:77), i.e. the
+// column sum of H^-1; H is symmetric, so that is (H^-1 1)[k] and ONE solve serves every query.
+extern "C" int mpsfm_integration_variances(const mpsfm_int_problem* P, int32_t device, int32_t use_sparse, int32_t n_query,
+                                           const int32_t* qx, const int32_t* qy, double rtol, int32_t max_iter,
+                                           double* var_out, double* field_out, mpsfm_int_summary* S) {
+  if (!P || !S) return ifail(MPSFM_EINVAL, "NULL argument");
+  if (n_query < 0 || (n_query > 0 && (!qx || !qy || !var_out))) return ifail(MPSFM_EINVAL, "query arrays are NULL");
+  if (!(rtol > 0.0) || max_iter <= 0) return ifail(MPSFM_EINVAL, "rtol / max_iter must be positive");
+  if (int rc = int_check(P, device)) return rc;
+  for (int i = 0; i < n_query; ++i)
+    if (qx[i] < 0 || qx[i] >= P->W || qy[i] < 0 || qy[i] >= P->H) return ifail(MPSFM_EINVAL, "query pixel outside the map");
+  INT_TRY(hipSetDevice(device));
+  std::memset(S, 0, sizeof(*S));
+  StreamGuard sg;
+  INT_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+  hipStream_t st = sg.st;
+  const int N = P->H * P->W;
+  IntSetup U;
+  if (int rc = int_setup(P, use_sparse != 0, false, st, U)) return rc;  // calculate_hessian applies no scale filter (:542)
+  IntDev& D = U.D;
+  hipEvent_t e0, e1;
+  INT_TRY(hipEventCreate(&e0)); INT_TRY(hipEventCreate(&e1));
+  INT_TRY(hipEventRecord(e0, st));
+  int_launch_prepare(P, U, st);
+  hipLaunchKernelGGL(k_int_weights, dim3(U.G), dim3(kIT), 0, st, D, P->k, P->lambda1, 0);  // init=False: weights from the checkpoint
+  hipLaunchKernelGGL(k_int_system, dim3(U.G), dim3(kIT), 0, st, D, P->lambda1);
+  hipLaunchKernelGGL(k_int_unit_rhs, dim3(U.G), dim3(kIT), 0, st, D);
+  int its = 0;
+  bool conv = false;
+  int rc = int_run_cg(D, U.G, st, rtol, max_iter, &its, &conv);
+  float ms = 0.f;
+  (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  S->ms = ms;
+  S->irls_iterations = 1;
+  S->cg_iters[0] = its;
+  S->cg_iterations_total = its;
+  S->changed = conv ? 1 : 0;
+  std::vector<double> host;
+  double* f = field_out;
+  if (!f) { host.resize((size_t)N); f = host.data(); }
+  INT_TRY(hipMemcpyAsync(f, D.z, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+  INT_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < n_query; ++i) var_out[i] = f[(size_t)qy[i] * P->W + qx[i]];
+  return 0;
 }

@@ -13,7 +13,7 @@ class Integration:
     conf_integration = dict(
         large_number=1e6, max_iter=10, tol=5e-2, step_size=1, cg_max_iter=5000, cg_tol=1e-3, lambda1=1, lambda2=1, k=1,
         depth_magnitude_multiplier=1, normals_magnitude_multiplier=1, scale_filter=True, scale_filter_factor=1.5,
-        robust_triangles=2,
+        robust_triangles=2, downscale_factor=2, downscaled=True, ignore_depths=True, int_cov_rtol=1e-10, int_cov_max_iter=50000,
     )
 
     def __init__(self):
@@ -24,6 +24,7 @@ class Integration:
         self.count_integrated = 0
         self.count_skipped = 0
         self.last_integration_summary = None
+        self.Hessian = None
 
     # the host object provides: self.mpsfm_rec, self.imid, self.image, self.camera (with sx, sy,
     # calibration_matrix()), self.depth (data, data_prior, uncertainty, valid), self.normals (data, uncertainty)
@@ -49,6 +50,10 @@ class Integration:
         return dict(kps=kps[mask], zvars3d=np.asarray(zvars3d)[mask], depth3d=np.asarray(depth3d)[mask],
                     K=[Kc[1, 1] * self.camera.sy, Kc[0, 0] * self.camera.sx, Kc[1, 2] * self.camera.sy, Kc[0, 2] * self.camera.sx]), True
 
+    def _solver_conf(self):
+        skip = ("robust_triangles", "downscale_factor", "downscaled", "ignore_depths", "int_cov_rtol", "int_cov_max_iter")
+        return {k: v for k, v in self.conf_integration.items() if k not in skip}
+
     def integrate(self, cache_device="cpu"):
         """Integrate depth map from normals with depth constraints (reference :133-137)."""
         assert self.image.has_pose and self.depth.activated, "Image not registered or depth map not activated"
@@ -60,7 +65,7 @@ class Integration:
 
         nunc = np.asarray(self.normals.uncertainty)
         nvar = np.stack([nunc[..., 0, 0], nunc[..., 1, 1], nunc[..., 2, 2]], -1) if nunc.ndim == 4 else nunc
-        conf = {k: v for k, v in self.conf_integration.items() if k != "robust_triangles"}
+        conf = self._solver_conf()
         depth, summary, wu, wv = capi.integrate_depth(
             self.depth.data_prior, self.depth.uncertainty, self.depth.valid, self.normals.data, nvar, self.depth.data, K, kps,
             depth3d, zvars3d, conf=conf, init=init, integrated=self.integrated, energy_old=self.energy_old or 0.0,
@@ -73,6 +78,110 @@ class Integration:
         self.count_skipped += 1
         self.depth.data = depth
         return True
+
+    # ---- uncertainty propagation (reference :522-629) ----------------------------------------------------
+    def calculate_hessian(self, downscaled, ignore_depths=None):
+        """reference :522-574.  The matrix itself is never assembled here (the device solve is matrix-free):
+        `self.Hessian` holds the inputs that define it plus, once computed, the field H^-1 1 from which every
+        query of `calculate_int_covs_at_points` is a gather."""
+        conf = self.conf_integration
+        if ignore_depths is None:
+            ignore_depths = conf["ignore_depths"]
+        kwargs, _ = self._prepare_integration_variables()
+        depth3d, zvars3d, kps, K = kwargs["depth3d"], kwargs["zvars3d"], kwargs["kps"], list(kwargs["K"])
+        prior, unc, valid, ckpt = self.depth.data_prior, self.depth.uncertainty, self.depth.valid, self.depth.data
+        normals, nunc = self.normals.data, np.asarray(self.normals.uncertainty)
+        full_shape = np.asarray(self.depth.data).shape
+        if downscaled:
+            fac = conf["downscale_factor"]
+            H, W = np.asarray(prior).shape
+            size = (int(W // fac), int(H // fac))
+            kps = (kps // fac).astype(int)
+            K = [v / fac for v in K]
+            prior, unc, ckpt = resize_linear(prior, size), resize_linear(unc, size), resize_linear(ckpt, size)
+            valid = np.floor(resize_linear(np.asarray(valid, np.float64), size) + 0.5) != 0   # uint8 resize, then astype(bool)
+            normals, nunc = self.normals.data_downscaled, np.asarray(self.normals.uncertainty_downscaled)
+        if not ignore_depths and len(kps):
+            # :283 ravels the (possibly downscaled) pixels with the FULL map shape; the flat ids index the solved map
+            ids = np.ravel_multi_index((kps[:, 1], kps[:, 0]), full_shape)
+            Hs, Ws = np.asarray(prior).shape
+            if ids.max() >= Hs * Ws:
+                raise IndexError("sparse id out of bounds for the downscaled map (same failure as the reference)")
+            kps = np.stack([ids % Ws, ids // Ws], 1)
+        nvar = np.stack([nunc[..., 0, 0], nunc[..., 1, 1], nunc[..., 2, 2]], -1) if nunc.ndim == 4 else nunc
+        self.Hessian = dict(depth_prior=prior, depth_uncertainty=unc, valid=valid, normals=normals, normals_var=nvar,
+                            depth_checkpoint=ckpt, K=K, kps=kps, depth3d=depth3d, zvars3d=zvars3d,
+                            use_sparse=not ignore_depths, shape=np.asarray(prior).shape, field=None, summary=None)
+        return self.Hessian
+
+    def calculate_int_covs_at_points(self, pts, verbose=False, Hessian=None, downscaled=None, ignore_depths=None):
+        """reference :576-600 + IntegrationUncertainty.solve :62-78 (sum of the solution column per query)."""
+        from ... import capi
+
+        conf = self.conf_integration
+        if downscaled is None:
+            downscaled = conf["downscaled"]
+        if Hessian is None:
+            if self.Hessian is None:
+                self.calculate_hessian(downscaled=downscaled, ignore_depths=ignore_depths)
+            Hessian = self.Hessian
+        pts = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+        kps = pts // conf["downscale_factor"] if downscaled else pts
+        xy = np.round(kps).astype(int)
+        Hs, Ws = Hessian["shape"]
+        np.ravel_multi_index(xy.T[::-1], (Hs, Ws))  # raises ValueError on an out-of-map query like the reference
+        if Hessian["field"] is None:
+            h = Hessian
+            _, summary, field = capi.integration_variances(
+                h["depth_prior"], h["depth_uncertainty"], h["valid"], h["normals"], h["normals_var"], h["depth_checkpoint"], h["K"],
+                np.zeros((0, 2), int), kps=h["kps"], depth3d=h["depth3d"], zvars3d=h["zvars3d"], use_sparse=h["use_sparse"],
+                conf=self._solver_conf(), rtol=conf["int_cov_rtol"], max_iter=conf["int_cov_max_iter"], return_field=True)
+            h["field"], h["summary"] = field, summary
+        return Hessian["field"][xy[:, 1], xy[:, 0]]
+
+    def calculate_int_covs_at_kps(self, Hessian=None, pts2d=None, downscaled=None):
+        """reference :602-616"""
+        kps = self.mpsfm_rec.keypoints(self.imid)
+        if pts2d is None:
+            pts2d = np.arange(len(kps))
+        else:
+            kps = kps[pts2d]
+        kps_down = kps * np.array([self.camera.sx, self.camera.sy])
+        log_uncert = self.calculate_int_covs_at_points(kps_down, Hessian=Hessian, downscaled=downscaled)
+        uncert = log_uncert * self.depth.data_prior_at_kps(kps) ** 2  # var(log d) = var(d) / d^2
+        self.depth.uncertainty_update[pts2d] = uncert
+        return uncert
+
+    def calculate_int_covs_for_entire_image(self, downscaled=None, ignore_depths=False):
+        """reference :618-629"""
+        nshape = np.asarray(self.depth.data).shape
+        xx, yy = np.meshgrid(np.arange(nshape[1]), np.arange(nshape[0]))
+        v = self.calculate_int_covs_at_points(np.array([xx.flatten(), yy.flatten()]).T, downscaled=downscaled,
+                                              ignore_depths=ignore_depths)
+        return v.reshape(nshape) * np.asarray(self.depth.data) ** 2
+
+
+def _linear_taps(n_src, n_dst):
+    """[n_dst, n_src] interpolation matrix of OpenCV's INTER_LINEAR along one axis: sample position
+    (i + 0.5) * n_src / n_dst - 0.5, replicated border, float32 coefficients."""
+    pos = (np.arange(n_dst) + 0.5) * (1.0 / (n_dst / n_src)) - 0.5
+    lo = np.floor(pos).astype(int)
+    frac = (pos - lo).astype(np.float32).astype(np.float64)
+    frac[(lo < 0) | (lo >= n_src - 1)] = 0.0
+    lo = np.clip(lo, 0, n_src - 1)
+    T = np.zeros((n_dst, n_src))
+    T[np.arange(n_dst), lo] += 1.0 - frac
+    T[np.arange(n_dst), np.minimum(lo + 1, n_src - 1)] += frac
+    return T
+
+
+def resize_linear(img, dsize):
+    """`cv2.resize(img, (w, h))` (bilinear) for one float64 channel — what the reference applies to the depth
+    prior, its variance and the checkpoint when `downscaled` (:241-259, :293-297).  cv2 is not available
+    offline: restated from OpenCV's sampling rule, exact 2x2 means for even sizes and factor 2."""
+    img = np.asarray(img, dtype=np.float64)
+    return _linear_taps(img.shape[0], int(dsize[1])) @ img @ _linear_taps(img.shape[1], int(dsize[0])).T
+
 
 
 def integrate_bundle(images, workers: int = 8, cache_device="cpu"):

@@ -10,9 +10,13 @@ from .integration import Integration
 
 
 class NumpyNormals:
-    def __init__(self, data, uncertainty):
+    def __init__(self, data, uncertainty, data_downscaled=None, uncertainty_downscaled=None):
         self.data = np.asarray(data, dtype=np.float64)                # [H,W,3]
         self.uncertainty = np.asarray(uncertainty, dtype=np.float64)  # [H,W,3,3]
+        # the reference's Normals object carries half-resolution maps from the normal estimator
+        # (scene/image/normals.py:196-233); tests pass them in
+        self.data_downscaled = None if data_downscaled is None else np.asarray(data_downscaled, dtype=np.float64)
+        self.uncertainty_downscaled = None if uncertainty_downscaled is None else np.asarray(uncertainty_downscaled, dtype=np.float64)
 
 
 class NumpyIntegrableImage(Integration):

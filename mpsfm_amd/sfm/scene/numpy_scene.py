@@ -231,6 +231,10 @@ class NumpyReconstruction:
     def registered_images(self):
         return {i: im for i, im in self.images.items() if im.has_pose}
 
+    def keypoints(self, imid):
+        """keypoints of image (reference reconstruction/base.py:85-87)"""
+        return self.images[imid].kps.copy()
+
     def point3D_coordinates(self, ids):
         return np.array([self.points3D[int(i)].xyz for i in ids], dtype=np.float64).reshape(-1, 3)
 

@@ -303,3 +303,68 @@ def integrate(inp: IntInputs, state: IntState | None = None, init=True, record=N
     state.integrated = True
     state.energy_old = energy
     return np.exp(z.reshape(H, W)).astype(np.float64), True, state, info
+
+
+# ---- row f4: uncertainty propagation (reference integration.py:51-79, 522-616) ----------------------------
+
+def calculate_hessian(inp: IntInputs, ignore_depths=True):
+    """calculate_hessian (:522-574) for the map in `inp` (already downscaled by the caller when the
+    reference would): calc_Amat at the checkpoint `depth_init`, weights recomputed from it (init=False),
+    no scale filter, sparse term only when not ignore_depths."""
+    conf = dict(inp.conf)
+    conf["scale_filter"] = False  # :542 calls process_sparse_depth only
+    P = prepare(IntInputs(**{**inp.__dict__, "conf": conf}))
+    H, W = P["shape"]
+    cam = CamData(H, W)
+    state = IntState()
+    Nz, Nu_p, Nv_p, _, _ = init_int_vars(cam, P["z"], inp.K, P["nx"], P["ny"], P["nz"], P["Vnx"], P["Vny"], P["Vnz"], conf, state,
+                                         init=False)
+    W4 = calc_Wpm(Nu_p, Nv_p, state.wu, state.wv)
+    A_mat, _ = calc_Amat(cam, Nz, W4, P["depth_precision"], P["sparse_precision"], P["sparse_ids"], conf,
+                         sparse_depth=not ignore_depths)
+    return A_mat
+
+
+def uncertainty_solve(hessian, xy, imshape, chunk_size=128):
+    """IntegrationUncertainty.solve (:62-78), literally: one unit right-hand side per query pixel, the
+    result is the SUM of the solution column (`x.sum(0)`, :77).  The reference factors with cholespy in
+    float32; this restatement uses SciPy's sparse LU in float64."""
+    from scipy.sparse import csc_matrix
+    from scipy.sparse.linalg import splu
+
+    lu = splu(csc_matrix(hessian))
+    n = hessian.shape[0]
+    xy = np.round(np.asarray(xy, dtype=np.float64)).astype(int).reshape(-1, 2)
+    out = []
+    for i in range(0, len(xy), chunk_size):
+        q = xy[i:i + chunk_size]
+        indices = np.ravel_multi_index(q.T[::-1], imshape[:2])
+        tgt = np.zeros((n, len(indices)))
+        tgt[(indices, np.arange(len(indices)))] = 1
+        out.append(lu.solve(tgt).sum(0))
+    return np.concatenate(out) if out else np.zeros(0)
+
+
+def resize_linear(img, dsize):
+    """cv2.resize(img, (w, h)) with the default INTER_LINEAR for a single-channel float64 image, restated
+    from OpenCV's documented sampling rule (pixel centres: src = (dst + 0.5) * scale - 0.5, border
+    replicated, interpolation coefficients held in float32).  cv2 is not importable here: unpinned."""
+    img = np.asarray(img, dtype=np.float64)
+    h, w = img.shape
+    dw, dh = int(dsize[0]), int(dsize[1])
+
+    def taps(n_src, n_dst):
+        scale = 1.0 / (n_dst / n_src)
+        f = (np.arange(n_dst) + 0.5) * scale - 0.5
+        i0 = np.floor(f).astype(int)
+        a = (f - i0).astype(np.float32)
+        lo = i0 < 0
+        i0[lo], a[lo] = 0, 0
+        hi = i0 >= n_src - 1
+        i0[hi], a[hi] = n_src - 1, 0
+        return i0, np.minimum(i0 + 1, n_src - 1), a.astype(np.float64)
+
+    x0, x1, ax = taps(w, dw)
+    y0, y1, ay = taps(h, dh)
+    rows = img[:, x0] * (1 - ax) + img[:, x1] * ax
+    return rows[y0] * (1 - ay)[:, None] + rows[y1] * ay[:, None]
