@@ -6,11 +6,17 @@
 // decisions from a handful of scalars.
 #include <algorithm>
 #include <chrono>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
+#include <tuple>
 #include <vector>
+
+#include <sched.h>
 
 #include "common.h"
 
@@ -52,12 +58,99 @@ static int dev_alloc(T** p, size_t count) {
   if (e != hipSuccess) return fail(MPSFM_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
   return 0;
 }
+// Uploads of caller / table memory go through a process-wide pinned staging buffer (two halves, the host copy
+// into one overlaps the DMA out of the other).  Handing pageable memory to hipMemcpy directly makes the
+// runtime pin and later unpin every source range: measured 17 ms of stall after a 40 MB table upload.
+struct Stager {
+  static constexpr size_t kHalf = (size_t)8 << 20;
+  std::mutex mu;
+  char* buf = nullptr;
+  hipStream_t st = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool busy[2] = {false, false};
+  int next = 0;
+  int init() {
+    if (buf) return 0;
+    if (hipHostMalloc((void**)&buf, 2 * kHalf, hipHostMallocDefault) != hipSuccess) { buf = nullptr; return fail(MPSFM_ENOMEM, "hipHostMalloc (staging) failed"); }
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    return 0;
+  }
+  // blocking from the caller's point of view only at drain()
+  int push(void* dst, const void* src, size_t bytes) {
+    const char* s = (const char*)src;
+    char* d = (char*)dst;
+    while (bytes > 0) {
+      const size_t n = std::min(bytes, kHalf);
+      const int hf = next;
+      next ^= 1;
+      if (busy[hf]) { HIP_TRY(hipEventSynchronize(ev[hf])); busy[hf] = false; }
+      std::memcpy(buf + (size_t)hf * kHalf, s, n);
+      HIP_TRY(hipMemcpyAsync(d, buf + (size_t)hf * kHalf, n, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipEventRecord(ev[hf], st));
+      busy[hf] = true;
+      s += n; d += n; bytes -= n;
+    }
+    return 0;
+  }
+  int drain() {
+    HIP_TRY(hipStreamSynchronize(st));
+    busy[0] = busy[1] = false;
+    return 0;
+  }
+};
+static Stager g_stagers[16];  // one per device ordinal
+static Stager& stager() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return g_stagers[(size_t)std::min(std::max(dev, 0), 15)];
+}
+
+// staged copy of host memory to the device, complete on return
+static int staged_h2d(void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  Stager& G = stager();
+  std::lock_guard<std::mutex> lk(G.mu);
+  if (int rc = G.init()) return rc;
+  if (int rc = G.push(dst, src, bytes)) return rc;
+  return G.drain();
+}
+
 template <typename T>
 static int dev_upload(T** p, const std::vector<T>& v) {
   int rc = dev_alloc(p, v.size());
   if (rc) return rc;
-  if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  return 0;
+  if (v.empty()) return 0;
+  Stager& G = stager();
+  std::lock_guard<std::mutex> lk(G.mu);
+  if ((rc = G.init())) return rc;
+  return G.push(*p, v.data(), v.size() * sizeof(T));  // build() drains once after the last table
+}
+// uninitialised host array (std::vector would zero-fill tens of MB on one thread)
+template <typename T>
+struct HostBuf {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  void alloc(size_t k) { p.reset(new T[std::max<size_t>(k, 1)]); n = k; }
+  size_t size() const { return n; }
+  T* data() { return p.get(); }
+  T& operator[](size_t i) { return p[i]; }
+};
+template <typename T>
+static int dev_upload(T** p, HostBuf<T>& v) {
+  int rc = dev_alloc(p, v.size());
+  if (rc) return rc;
+  if (v.size() == 0) return 0;
+  Stager& G = stager();
+  std::lock_guard<std::mutex> lk(G.mu);
+  if ((rc = G.init())) return rc;
+  return G.push(*p, v.data(), v.size() * sizeof(T));
+}
+static int drain_uploads() {
+  Stager& G = stager();
+  std::lock_guard<std::mutex> lk(G.mu);
+  return G.buf ? G.drain() : 0;
 }
 
 }  // namespace mpsfm
@@ -162,6 +255,41 @@ static int allreduce_dev(mpsfm_ba_handle* h, double* buf, int64_t count) {
 
 struct Blk { int32_t cam; int32_t key; uint8_t kind; int64_t src; };
 
+// ---- host threads for the table build (plain std::thread: no OpenMP runtime beside torch's) -------
+// CPUs this process may use: scheduler affinity capped by the cgroup quota; MPSFM_HOST_THREADS overrides.
+static int host_threads() {
+  static const int n = [] {
+    if (const char* e = std::getenv("MPSFM_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) return std::min(v, 64); }
+    int cpus = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::max(1, CPU_COUNT(&set));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char a[64]; double per = 0.0;
+      if (std::fscanf(f, "%63s %lf", a, &per) == 2 && std::strcmp(a, "max") != 0 && per > 0.0)
+        cpus = std::min(cpus, std::max(1, (int)(std::atof(a) / per + 0.5)));
+      std::fclose(f);
+    }
+    return std::min(cpus, 32);
+  }();
+  return n;
+}
+// f(part, nparts) on nparts threads (the calling thread takes part 0)
+template <class F>
+static void run_parts(int nparts, F&& f) {
+  std::vector<std::thread> th;
+  th.reserve((size_t)std::max(nparts - 1, 0));
+  for (int t = 1; t < nparts; ++t) th.emplace_back([&f, t, nparts] { f(t, nparts); });
+  f(0, nparts);
+  for (auto& x : th) x.join();
+}
+// f(begin, end) over [0, n) cut into nearly equal contiguous parts
+template <class F>
+static void parallel_ranges(int64_t n, int64_t min_grain, F&& f) {
+  const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / std::max<int64_t>(min_grain, 1)));
+  if (parts <= 1) { f((int64_t)0, n); return; }
+  run_parts(parts, [&](int t, int np) { f(n * t / np, n * (t + 1) / np); });
+}
+
 // Build the re-ordered, chunked record tables and upload everything.
 static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_state* st) {
   const int nc = P->n_cams, npu = P->n_pts;
@@ -194,67 +322,110 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   h->nt = (h->n + 31) / 32;
   const std::vector<int32_t>& slot = h->cam_slot_h;
 
-  // -- residual blocks grouped by landmark
-  std::vector<int64_t> pstart((size_t)npu + 1, 0);
-  for (int64_t i = 0; i < P->n_obs; ++i) pstart[P->obs_pt[i] + 1]++;
-  for (int64_t i = 0; i < P->n_dobs; ++i) pstart[P->dobs_pt[i] + 1]++;
-  for (int p = 0; p < npu; ++p) pstart[p + 1] += pstart[p];
-  std::vector<Blk> blks((size_t)pstart[npu]);
-  {
-    std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
-    for (int64_t i = 0; i < P->n_obs; ++i) {
-      const int c = P->obs_cam[i];
-      blks[fill[P->obs_pt[i]]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 0, i};
-    }
-    for (int64_t i = 0; i < P->n_dobs; ++i) {
-      const int c = P->dobs_cam[i];
-      if (!(P->dobs_depth[i] > 0.0)) return fail(MPSFM_EINVAL, "depth prior must be positive");
-      blks[fill[P->dobs_pt[i]]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 1, i};
-    }
-  }
-  lap("group blocks by landmark");
-  // -- merged records per landmark; fixed blocks aside
+  // -- residual blocks grouped by landmark and merged into records.  Every host thread owns a contiguous
+  //    landmark range: it scans the block lists for its landmarks (counting sort), orders each landmark's
+  //    blocks by camera slot and merges a reprojection and a depth block of one (camera, landmark) pair
+  //    into one record; fixed blocks (constant camera and constant landmark) are kept aside.
   struct Rec { int32_t cam; int32_t slot; uint32_t flags; double u, v, d, m, a; };
-  std::vector<Rec> recs; recs.reserve(blks.size());
-  std::vector<int64_t> prec((size_t)npu + 1, 0);  // record range per caller landmark
-  std::vector<Rec> fixed;
-  std::vector<int32_t> fixed_pt;
   auto deff = [&](int cam, int64_t src) {
     double b = 0.0, s = 0.0;
     if (P->shift_logscale) { b = P->shift_logscale[2 * cam]; s = P->shift_logscale[2 * cam + 1]; }
     return P->dobs_depth[src] * std::exp(s) + b;
   };
-  for (int p = 0; p < npu; ++p) {
-    auto b0 = blks.begin() + pstart[p], b1 = blks.begin() + pstart[p + 1];
-    std::sort(b0, b1, [](const Blk& x, const Blk& y) {
-      if (x.key != y.key) return x.key < y.key;
-      if (x.cam != y.cam) return x.cam < y.cam;
-      if (x.kind != y.kind) return x.kind < y.kind;
-      return x.src < y.src;
-    });
-    prec[p] = (int64_t)recs.size();
-    for (auto it = b0; it != b1;) {
-      auto je = it;
-      while (je != b1 && je->cam == it->cam) ++je;
-      auto mid = it;
-      while (mid != je && mid->kind == 0) ++mid;
-      const int64_t nr = mid - it, nd = je - mid;
-      const bool is_fixed = (slot[it->cam] < 0) && P->pt_const[p];
-      for (int64_t k = 0; k < std::max(nr, nd); ++k) {
-        Rec r{it->cam, slot[it->cam], 0, 0, 0, 1.0, 0.0, 1.0};
-        if (k < nr) { const int64_t s = (it + k)->src; r.flags |= kRecHasReproj; r.u = P->obs_xy[2 * s]; r.v = P->obs_xy[2 * s + 1]; }
-        if (k < nd) {
-          const int64_t s = (mid + k)->src;
-          r.flags |= kRecHasDepth; r.d = deff(it->cam, s); r.m = P->dobs_magnitude[s]; r.a = P->dobs_param[s];
-          if (!(r.d > 0.0)) return fail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive");
-        }
-        if (is_fixed) { fixed.push_back(r); fixed_pt.push_back(p); }
-        else recs.push_back(r);
+  struct MergePart {
+    int p0 = 0, p1 = 0, err = 0;
+    std::vector<Rec> recs, fixed;
+    std::vector<int32_t> fixed_pt;
+    std::vector<int64_t> nrec_of;  // records per landmark of the range
+  };
+  const int mparts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (P->n_obs + P->n_dobs) / 65536));
+  std::vector<MergePart> mp((size_t)mparts);
+  run_parts(mparts, [&](int t, int nparts) {
+    MergePart& M = mp[(size_t)t];
+    M.p0 = (int)((int64_t)npu * t / nparts); M.p1 = (int)((int64_t)npu * (t + 1) / nparts);
+    const int p0 = M.p0, np_loc = M.p1 - M.p0;
+    std::vector<int64_t> pstart((size_t)np_loc + 1, 0);
+    for (int64_t i = 0; i < P->n_obs; ++i) { const unsigned q = (unsigned)(P->obs_pt[i] - p0); if (q < (unsigned)np_loc) pstart[q + 1]++; }
+    for (int64_t i = 0; i < P->n_dobs; ++i) { const unsigned q = (unsigned)(P->dobs_pt[i] - p0); if (q < (unsigned)np_loc) pstart[q + 1]++; }
+    for (int q = 0; q < np_loc; ++q) pstart[q + 1] += pstart[q];
+    std::vector<Blk> blks((size_t)pstart[np_loc]);
+    {
+      std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
+      for (int64_t i = 0; i < P->n_obs; ++i) {
+        const unsigned q = (unsigned)(P->obs_pt[i] - p0);
+        if (q >= (unsigned)np_loc) continue;
+        const int c = P->obs_cam[i];
+        blks[fill[q]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 0, i};
       }
-      it = je;
+      for (int64_t i = 0; i < P->n_dobs; ++i) {
+        const unsigned q = (unsigned)(P->dobs_pt[i] - p0);
+        if (q >= (unsigned)np_loc) continue;
+        const int c = P->dobs_cam[i];
+        if (!(P->dobs_depth[i] > 0.0)) { M.err = 1; return; }
+        blks[fill[q]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 1, i};
+      }
+    }
+    M.recs.reserve(blks.size());
+    M.nrec_of.assign((size_t)np_loc, 0);
+    for (int q = 0; q < np_loc; ++q) {
+      const int p = p0 + q;
+      auto b0 = blks.begin() + pstart[q], b1 = blks.begin() + pstart[q + 1];
+      std::sort(b0, b1, [](const Blk& x, const Blk& y) {
+        if (x.key != y.key) return x.key < y.key;
+        if (x.cam != y.cam) return x.cam < y.cam;
+        if (x.kind != y.kind) return x.kind < y.kind;
+        return x.src < y.src;
+      });
+      const size_t before = M.recs.size();
+      for (auto it = b0; it != b1;) {
+        auto je = it;
+        while (je != b1 && je->cam == it->cam) ++je;
+        auto mid = it;
+        while (mid != je && mid->kind == 0) ++mid;
+        const int64_t nr = mid - it, nd = je - mid;
+        const bool is_fixed = (slot[it->cam] < 0) && P->pt_const[p];
+        for (int64_t k = 0; k < std::max(nr, nd); ++k) {
+          Rec r{it->cam, slot[it->cam], 0, 0, 0, 1.0, 0.0, 1.0};
+          if (k < nr) { const int64_t s = (it + k)->src; r.flags |= kRecHasReproj; r.u = P->obs_xy[2 * s]; r.v = P->obs_xy[2 * s + 1]; }
+          if (k < nd) {
+            const int64_t s = (mid + k)->src;
+            r.flags |= kRecHasDepth; r.d = deff(it->cam, s); r.m = P->dobs_magnitude[s]; r.a = P->dobs_param[s];
+            if (!(r.d > 0.0)) { M.err = 2; return; }
+          }
+          if (is_fixed) { M.fixed.push_back(r); M.fixed_pt.push_back(p); }
+          else M.recs.push_back(r);
+        }
+        it = je;
+      }
+      M.nrec_of[(size_t)q] = (int64_t)(M.recs.size() - before);
+    }
+  });
+  for (const MergePart& M : mp) {
+    if (M.err == 1) return fail(MPSFM_EINVAL, "depth prior must be positive");
+    if (M.err == 2) return fail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive");
+  }
+  lap("group + merge (threads)");
+  std::vector<int64_t> prec((size_t)npu + 1, 0);  // record range per caller landmark
+  std::vector<Rec> recs;
+  std::vector<Rec> fixed;
+  std::vector<int32_t> fixed_pt;
+  {
+    std::vector<int64_t> base((size_t)mparts + 1, 0);
+    for (int t = 0; t < mparts; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)mp[(size_t)t].recs.size();
+    recs.resize((size_t)base[(size_t)mparts]);
+    run_parts(mparts, [&](int t, int) {
+      MergePart& M = mp[(size_t)t];
+      std::copy(M.recs.begin(), M.recs.end(), recs.begin() + base[(size_t)t]);
+      int64_t o = base[(size_t)t];
+      for (int q = 0; q < M.p1 - M.p0; ++q) { prec[(size_t)(M.p0 + q)] = o; o += M.nrec_of[(size_t)q]; }
+      std::vector<Rec>().swap(M.recs);
+    });
+    prec[(size_t)npu] = base[(size_t)mparts];
+    for (MergePart& M : mp) {
+      fixed.insert(fixed.end(), M.fixed.begin(), M.fixed.end());
+      fixed_pt.insert(fixed_pt.end(), M.fixed_pt.begin(), M.fixed_pt.end());
     }
   }
-  prec[npu] = (int64_t)recs.size();
   h->nfixed = (int64_t)fixed.size();
   h->nblocks_total = P->n_obs + P->n_dobs;
 
@@ -269,25 +440,42 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     // cameras, which keeps the set of S blocks a chunk touches small
     struct Key { uint64_t k1, k2; int32_t p; };
     std::vector<Key> keyed(order.size());
-    for (size_t q = 0; q < order.size(); ++q) {
-      const int pnt = order[q];
-      const int64_t n_p = prec[pnt + 1] - prec[pnt];
-      uint64_t key[2] = {0, 0};
-      for (int64_t k = 0; k < 6; ++k) {
-        uint64_t sk = 0xffff;
-        if (k < n_p && recs[prec[pnt] + k].slot >= 0) sk = (uint64_t)std::min(recs[prec[pnt] + k].slot, 0xfffe);
-        key[k / 4] = (key[k / 4] << 16) | sk;
-      }
-      key[1] = (key[1] << 32) | (uint64_t)std::min<int64_t>(n_p, 0xffffffff);
-      keyed[q] = Key{key[0], key[1], pnt};
-    }
-    std::sort(keyed.begin(), keyed.end(), [](const Key& a, const Key& b) {
+    auto key_less = [](const Key& a, const Key& b) {
       if (a.k1 != b.k1) return a.k1 < b.k1;
       if (a.k2 != b.k2) return a.k2 < b.k2;
       return a.p < b.p;
+    };
+    // sorted runs per thread, then pairwise merges (the order is total, so the result does not depend on the split)
+    const int sparts = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), order.size() / 8192));
+    std::vector<size_t> cut((size_t)sparts + 1);
+    for (int t = 0; t <= sparts; ++t) cut[(size_t)t] = order.size() * (size_t)t / (size_t)sparts;
+    run_parts(sparts, [&](int t, int) {
+      for (size_t q = cut[(size_t)t]; q < cut[(size_t)t + 1]; ++q) {
+        const int pnt = order[q];
+        const int64_t n_p = prec[pnt + 1] - prec[pnt];
+        uint64_t key[2] = {0, 0};
+        for (int64_t k = 0; k < 6; ++k) {
+          uint64_t sk = 0xffff;
+          if (k < n_p && recs[prec[pnt] + k].slot >= 0) sk = (uint64_t)std::min(recs[prec[pnt] + k].slot, 0xfffe);
+          key[k / 4] = (key[k / 4] << 16) | sk;
+        }
+        key[1] = (key[1] << 32) | (uint64_t)std::min<int64_t>(n_p, 0xffffffff);
+        keyed[q] = Key{key[0], key[1], pnt};
+      }
+      std::sort(keyed.begin() + (std::ptrdiff_t)cut[(size_t)t], keyed.begin() + (std::ptrdiff_t)cut[(size_t)t + 1], key_less);
     });
+    for (int width = 1; width < sparts; width *= 2) {
+      std::vector<int> lefts;
+      for (int t = 0; t + width < sparts; t += 2 * width) lefts.push_back(t);
+      run_parts((int)lefts.size(), [&](int j, int) {
+        const int t = lefts[(size_t)j];
+        std::inplace_merge(keyed.begin() + (std::ptrdiff_t)cut[(size_t)t], keyed.begin() + (std::ptrdiff_t)cut[(size_t)(t + width)],
+                           keyed.begin() + (std::ptrdiff_t)cut[(size_t)std::min(t + 2 * width, sparts)], key_less);
+      });
+    }
     for (size_t q = 0; q < order.size(); ++q) order[q] = keyed[q].p;
   }
+  lap("sort landmarks by key");
   // landmarks whose track does not fit one chunk are swept by a workgroup of their own
   auto is_long = [&](int p) {
     const int64_t r_p = prec[p + 1] - prec[p];
@@ -297,7 +485,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       if (recs[r].slot >= 0 && recs[r].slot != last) { ++distinct; last = recs[r].slot; }
     return distinct > kLocalCamsMax;
   };
-  auto first_long = std::stable_partition(order.begin(), order.end(), [&](int p) { return !is_long(p); });
+  std::vector<uint8_t> long_flag((size_t)npu + 1, 0);
+  parallel_ranges((int64_t)order.size(), 8192, [&](int64_t q0, int64_t q1) {
+    for (int64_t q = q0; q < q1; ++q) long_flag[(size_t)order[(size_t)q]] = is_long(order[(size_t)q]) ? 1 : 0;
+  });
+  auto first_long = std::stable_partition(order.begin(), order.end(), [&](int p) { return !long_flag[(size_t)p]; });
   h->np_chunked = (int64_t)(first_long - order.begin());
   const int64_t n_long = (int64_t)(order.end() - first_long);
   {
@@ -311,153 +503,228 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   for (int64_t k = 0; k < h->np; ++k) inv[order[k]] = (int32_t)k;
 
   lap("order landmarks");
-  // -- chunking
+  // -- chunking.  Pass 1 (sequential, greedy): cut the ordered landmarks into chunks and collect each chunk's
+  //    sorted camera slots.  Pass 2 (host threads over contiguous chunk ranges): records, local camera
+  //    indices and the block-major Schur pair tables of every chunk.
   std::vector<ChunkHdr> chunks;
   std::vector<int32_t> chunk_cams;
-  std::vector<int32_t> rec_cam, rec_pt, pt_rec_start((size_t)h->np + 1, 0);
+  HostBuf<int32_t> rec_cam, rec_pt;
+  std::vector<int32_t> pt_rec_start((size_t)h->np + 1, 0);
   std::vector<uint32_t> blk_desc, ents;          // Schur pairs grouped by destination block, per chunk
   std::vector<int32_t> blk_ent_start;
-  struct PairEnt { uint16_t key; uint32_t ent; };
-  std::vector<PairEnt> pe, pe_sorted;
-  std::vector<std::pair<int, int>> blk_order;    // (count, first index into pe) per block of the open chunk
-  std::vector<uint32_t> rec_meta;
+  HostBuf<uint32_t> rec_meta;
   std::vector<uint16_t> pt_kv((size_t)h->np + 1, 0xffff);
-  std::vector<double> rec_xy, rec_d, rec_m, rec_a;
-  rec_cam.reserve(recs.size()); rec_pt.reserve(recs.size()); rec_meta.reserve(recs.size());
-  rec_xy.reserve(2 * recs.size()); rec_d.reserve(recs.size()); rec_m.reserve(recs.size()); rec_a.reserve(recs.size());
+  HostBuf<double> rec_xy, rec_d, rec_m, rec_a;
+  int64_t nrec_total = 0;
   int64_t nblk_reduced = 0;
   double nvarpts = 0;
   {
-    std::vector<int32_t> cur_cams;  // sorted slots of the open chunk
-    int64_t c_first = 0, c_nrec = 0;  // first landmark (re-ordered index), records
-    auto close_chunk = [&](int64_t end_pt) {
-      if (end_pt == c_first) return;
-      ChunkHdr H{};
-      H.rec0 = (int32_t)rec_cam.size(); H.pt0 = (int32_t)c_first; H.npt = (int32_t)(end_pt - c_first);
-      H.cam0 = (int32_t)chunk_cams.size(); H.ncam = (int32_t)cur_cams.size();
-      pe.clear();
-      for (int64_t k = c_first; k < end_pt; ++k) {
-        const int p = order[k];
-        pt_rec_start[k] = (int32_t)rec_cam.size();
-        const int rbase = (int)rec_cam.size() - H.rec0;  // chunk-relative index of this landmark's first record
-        int kv = 0;
-        for (int64_t r = prec[p]; r < prec[p + 1]; ++r) {
-          const Rec& R = recs[r];
-          uint32_t lcam = kLcamConst;
-          if (R.slot >= 0) {
-            lcam = (uint32_t)(std::lower_bound(cur_cams.begin(), cur_cams.end(), R.slot) - cur_cams.begin());
-            ++kv;
+    std::vector<int64_t> rec_off((size_t)h->np_chunked + 1, 0);  // first record of every chunked landmark
+    for (int64_t k = 0; k < h->np_chunked; ++k) rec_off[(size_t)k + 1] = rec_off[(size_t)k] + (prec[order[k] + 1] - prec[order[k]]);
+    {
+      // The greedy cut is sequential by nature; the ordered landmarks are therefore split into a FIXED number
+      // of segments (independent of the thread count, so the tables are the same on every machine), each cut
+      // greedily on its own with a forced chunk boundary at the segment ends.
+      struct Seg { std::vector<ChunkHdr> chunks; std::vector<int32_t> cams; };
+      const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(64, h->np_chunked / 4096));
+      std::vector<Seg> segs((size_t)nseg);
+      auto cut_segment = [&](int sidx) {
+        Seg& G = segs[(size_t)sidx];
+        const int64_t k0 = h->np_chunked * sidx / nseg, k1 = h->np_chunked * (sidx + 1) / nseg;
+        std::vector<int32_t> cur_cams, pc, uni;  // sorted slots of the open chunk
+        int64_t c_first = k0, c_nrec = 0;
+        auto close_chunk = [&](int64_t end_pt) {
+          if (end_pt == c_first) return;
+          ChunkHdr H{};
+          H.rec0 = (int32_t)rec_off[(size_t)c_first]; H.nrec = (int32_t)(rec_off[(size_t)end_pt] - rec_off[(size_t)c_first]);
+          H.pt0 = (int32_t)c_first; H.npt = (int32_t)(end_pt - c_first);
+          H.cam0 = (int32_t)G.cams.size(); H.ncam = (int32_t)cur_cams.size();  // segment-local for now
+          G.cams.insert(G.cams.end(), cur_cams.begin(), cur_cams.end());
+          G.chunks.push_back(H);
+          cur_cams.clear(); c_first = end_pt; c_nrec = 0;
+        };
+        for (int64_t k = k0; k < k1; ++k) {
+          const int p = order[k];
+          const int64_t r_p = prec[p + 1] - prec[p];
+          pc.clear();
+          for (int64_t r = prec[p]; r < prec[p + 1]; ++r) if (recs[r].slot >= 0) pc.push_back(recs[r].slot);
+          pc.erase(std::unique(pc.begin(), pc.end()), pc.end());  // records are slot-sorted
+          const bool subset = std::includes(cur_cams.begin(), cur_cams.end(), pc.begin(), pc.end());
+          size_t nuni = cur_cams.size();
+          if (!subset) {
+            uni.clear();
+            std::set_union(cur_cams.begin(), cur_cams.end(), pc.begin(), pc.end(), std::back_inserter(uni));
+            nuni = uni.size();
           }
-          rec_cam.push_back(R.cam); rec_pt.push_back((int32_t)k);
-          rec_meta.push_back(lcam | ((uint32_t)(k - c_first) << 8) | R.flags);
-          rec_xy.push_back(R.u); rec_xy.push_back(R.v); rec_d.push_back(R.d); rec_m.push_back(R.m); rec_a.push_back(R.a);
-          nblk_reduced += ((R.flags & kRecHasReproj) ? 1 : 0) + ((R.flags & kRecHasDepth) ? 1 : 0);
+          const bool too_big = (c_nrec + r_p > kObsMax) || (k - c_first + 1 > kPtsMax) || ((int)nuni > kLocalCamsMax);
+          if (k > c_first && too_big) {
+            close_chunk(k);
+            cur_cams = pc;
+          } else if (!subset) {
+            cur_cams.swap(uni);
+          }
+          c_nrec += r_p;
         }
-        if (!P->pt_const[p]) {
-          pt_kv[k] = (uint16_t)kv;
-          nvarpts += 1;
-          // Schur pairs of this landmark: records rbase .. rbase+kv-1 have variable cameras (slot-sorted)
-          const uint32_t lpt = (uint32_t)(k - c_first);
-          for (int i = 0; i < kv; ++i) {
-            const uint32_t li = rec_meta[H.rec0 + rbase + i] & 0xff;
-            for (int j = i; j < kv; ++j) {
-              const uint32_t lj = rec_meta[H.rec0 + rbase + j] & 0xff;
-              pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + i) | ((uint32_t)(rbase + j) << 8) | (lpt << 16)});
-              // two records of one camera: the diagonal block needs B + B^T
-              if (li == lj && i != j)
-                pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + j) | ((uint32_t)(rbase + i) << 8) | (lpt << 16)});
+        close_chunk(k1);
+      };
+      run_parts(std::min(host_threads(), nseg), [&](int t, int nparts) { for (int sidx = t; sidx < nseg; sidx += nparts) cut_segment(sidx); });
+      for (Seg& G : segs) {
+        const int32_t cbase = (int32_t)chunk_cams.size();
+        for (ChunkHdr& H : G.chunks) { H.cam0 += cbase; chunks.push_back(H); }
+        chunk_cams.insert(chunk_cams.end(), G.cams.begin(), G.cams.end());
+      }
+    }
+    lap("chunk boundaries");
+    const size_t nrec_chunked = (size_t)rec_off[(size_t)h->np_chunked];
+    nrec_total = (int64_t)nrec_chunked;
+    for (int64_t k = h->np_chunked; k < h->np_chunked + n_long; ++k) nrec_total += prec[order[k] + 1] - prec[order[k]];
+    if (nrec_total > (int64_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "more than 2^31 records on one device");
+    const size_t nr = (size_t)nrec_total;
+    rec_cam.alloc(nr); rec_pt.alloc(nr); rec_meta.alloc(nr); rec_xy.alloc(2 * nr); rec_d.alloc(nr); rec_m.alloc(nr); rec_a.alloc(nr);
+    lap("size record arrays");
+    struct PairEnt { uint16_t key; uint32_t ent; };
+    struct ChunkPart {
+      std::vector<uint32_t> blk_desc, ents;
+      std::vector<int32_t> blk_ent_start;
+      int64_t nblk_reduced = 0;
+      double nvarpts = 0;
+    };
+    const int nch = (int)chunks.size();
+    const int cparts = std::max(1, std::min(host_threads(), nch / 64));
+    std::vector<ChunkPart> cp((size_t)cparts);
+    run_parts(cparts, [&](int t, int nparts) {
+      ChunkPart& C = cp[(size_t)t];
+      std::vector<PairEnt> pe, pe_sorted;
+      std::vector<std::pair<int, int>> blk_order, items;  // (count, first index into pe)
+      std::vector<int32_t> cnt;
+      for (int c = (int)((int64_t)nch * t / nparts); c < (int)((int64_t)nch * (t + 1) / nparts); ++c) {
+        ChunkHdr& H = chunks[(size_t)c];
+        const int32_t* cams = chunk_cams.data() + H.cam0;
+        const int64_t c_first = H.pt0, end_pt = (int64_t)H.pt0 + H.npt;
+        pe.clear();
+        int64_t w = H.rec0;  // next record
+        for (int64_t k = c_first; k < end_pt; ++k) {
+          const int p = order[k];
+          pt_rec_start[(size_t)k] = (int32_t)w;
+          const int rbase = (int)(w - H.rec0);  // chunk-relative index of this landmark's first record
+          int kv = 0;
+          for (int64_t r = prec[p]; r < prec[p + 1]; ++r, ++w) {
+            const Rec& R = recs[r];
+            uint32_t lcam = kLcamConst;
+            if (R.slot >= 0) {
+              lcam = (uint32_t)(std::lower_bound(cams, cams + H.ncam, R.slot) - cams);
+              ++kv;
+            }
+            rec_cam[(size_t)w] = R.cam; rec_pt[(size_t)w] = (int32_t)k;
+            rec_meta[(size_t)w] = lcam | ((uint32_t)(k - c_first) << 8) | R.flags;
+            rec_xy[2 * (size_t)w] = R.u; rec_xy[2 * (size_t)w + 1] = R.v; rec_d[(size_t)w] = R.d; rec_m[(size_t)w] = R.m; rec_a[(size_t)w] = R.a;
+            C.nblk_reduced += ((R.flags & kRecHasReproj) ? 1 : 0) + ((R.flags & kRecHasDepth) ? 1 : 0);
+          }
+          if (!P->pt_const[p]) {
+            pt_kv[(size_t)k] = (uint16_t)kv;
+            C.nvarpts += 1;
+            // Schur pairs of this landmark: records rbase .. rbase+kv-1 have variable cameras (slot-sorted)
+            const uint32_t lpt = (uint32_t)(k - c_first);
+            for (int i = 0; i < kv; ++i) {
+              const uint32_t li = rec_meta[(size_t)H.rec0 + rbase + i] & 0xff;
+              for (int j = i; j < kv; ++j) {
+                const uint32_t lj = rec_meta[(size_t)H.rec0 + rbase + j] & 0xff;
+                pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + i) | ((uint32_t)(rbase + j) << 8) | (lpt << 16)});
+                // two records of one camera: the diagonal block needs B + B^T
+                if (li == lj && i != j)
+                  pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + j) | ((uint32_t)(rbase + i) << 8) | (lpt << 16)});
+              }
             }
           }
         }
+        // group the pairs by destination block (counting sort on li*ncam+lj); heaviest blocks first
+        {
+          const int nl = std::max(H.ncam, 1);
+          cnt.assign((size_t)nl * nl + 1, 0);
+          for (const PairEnt& e : pe) cnt[(size_t)(e.key & 0xff) * nl + (e.key >> 8) + 1]++;
+          for (size_t q = 1; q < cnt.size(); ++q) cnt[q] += cnt[q - 1];
+          pe_sorted.resize(pe.size());
+          for (const PairEnt& e : pe) pe_sorted[(size_t)cnt[(size_t)(e.key & 0xff) * nl + (e.key >> 8)]++] = e;
+          pe.swap(pe_sorted);
+        }
+        blk_order.clear();
+        for (size_t i = 0; i < pe.size();) {
+          size_t j = i;
+          while (j < pe.size() && pe[j].key == pe[i].key) ++j;
+          blk_order.emplace_back((int)(j - i), (int)i);
+          i = j;
+        }
+        std::stable_sort(blk_order.begin(), blk_order.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+        // work items: runs of at most kItemPairs pairs of one block.  Block-major: all items of a block are
+        // neighbours, so the flush combines them (one atomic pass per block and round)
+        items.clear();
+        for (const auto& bo : blk_order)
+          for (int q = 0; q < bo.first; q += kItemPairs) items.emplace_back(std::min(kItemPairs, bo.first - q), bo.second + q);
+        H.blk0 = (int32_t)C.blk_desc.size();  // thread-local for now
+        H.ent0 = (int32_t)C.ents.size();
+        H.nent = (int32_t)pe.size();
+        H.nblk = (int32_t)items.size();
+        for (const auto& it : items) {
+          C.blk_desc.push_back(pe[(size_t)it.second].key);
+          C.blk_ent_start.push_back((int32_t)(C.ents.size() - (size_t)H.ent0));
+          for (int q = 0; q < it.first; ++q) C.ents.push_back(pe[(size_t)(it.second + q)].ent);
+        }
+        C.blk_ent_start.push_back((int32_t)(C.ents.size() - (size_t)H.ent0));  // per-chunk sentinel
       }
-      H.nrec = (int32_t)rec_cam.size() - H.rec0;
-      // group the pairs by destination block (counting sort on li*64+lj); heaviest blocks first
-      {
-        static thread_local std::vector<int32_t> cnt;
-        cnt.assign(kLocalCamsMax * kLocalCamsMax + 1, 0);
-        for (const PairEnt& e : pe) cnt[(e.key & 0xff) * kLocalCamsMax + (e.key >> 8) + 1]++;
-        for (size_t q = 1; q < cnt.size(); ++q) cnt[q] += cnt[q - 1];
-        pe_sorted.resize(pe.size());
-        for (const PairEnt& e : pe) pe_sorted[cnt[(e.key & 0xff) * kLocalCamsMax + (e.key >> 8)]++] = e;
-        pe.swap(pe_sorted);
-      }
-      blk_order.clear();
-      for (size_t i = 0; i < pe.size();) {
-        size_t j = i;
-        while (j < pe.size() && pe[j].key == pe[i].key) ++j;
-        blk_order.emplace_back((int)(j - i), (int)i);
-        i = j;
-      }
-      std::stable_sort(blk_order.begin(), blk_order.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
-      // work items: runs of at most kItemPairs pairs of one block; heaviest first
-      H.blk0 = (int32_t)blk_desc.size();
-      H.ent0 = (int32_t)ents.size();
-      H.nent = (int32_t)pe.size();
-      // block-major: all items of a block are neighbours, so the flush combines them (one atomic pass per
-      // block and round); blocks are already ordered heaviest first
-      std::vector<std::pair<int, int>> items;  // (count, first index into pe)
-      for (const auto& bo : blk_order)
-        for (int t = 0; t < bo.first; t += kItemPairs) items.emplace_back(std::min(kItemPairs, bo.first - t), bo.second + t);
-      H.nblk = (int32_t)items.size();
-      for (const auto& it : items) {
-        blk_desc.push_back(pe[it.second].key);
-        blk_ent_start.push_back((int32_t)(ents.size() - (size_t)H.ent0));
-        for (int t = 0; t < it.first; ++t) ents.push_back(pe[it.second + t].ent);
-      }
-      blk_ent_start.push_back((int32_t)(ents.size() - (size_t)H.ent0));  // per-chunk sentinel
-      chunk_cams.insert(chunk_cams.end(), cur_cams.begin(), cur_cams.end());
-      chunks.push_back(H);
-      cur_cams.clear(); c_first = end_pt; c_nrec = 0;
-    };
-    std::vector<int32_t> pc, uni;
-    for (int64_t k = 0; k < h->np_chunked; ++k) {
-      const int p = order[k];
-      const int64_t r_p = prec[p + 1] - prec[p];
-      pc.clear();
-      for (int64_t r = prec[p]; r < prec[p + 1]; ++r) if (recs[r].slot >= 0) pc.push_back(recs[r].slot);
-      pc.erase(std::unique(pc.begin(), pc.end()), pc.end());  // records are slot-sorted
-      uni.clear();
-      std::set_union(cur_cams.begin(), cur_cams.end(), pc.begin(), pc.end(), std::back_inserter(uni));
-      const bool too_big = (c_nrec + r_p > kObsMax) || (k - c_first + 1 > kPtsMax) || ((int)uni.size() > kLocalCamsMax);
-      if (k > c_first && too_big) {
-        close_chunk(k);
-        uni = pc;
-      }
-      cur_cams = uni;
-      c_nrec += r_p;
+    });
+    lap("chunk records + pairs (threads)");
+    // concatenate the per-thread pair tables and make the chunk offsets global
+    std::vector<size_t> bbase((size_t)cparts + 1, 0), ebase((size_t)cparts + 1, 0), sbase((size_t)cparts + 1, 0);
+    for (int t = 0; t < cparts; ++t) {
+      bbase[(size_t)t + 1] = bbase[(size_t)t] + cp[(size_t)t].blk_desc.size();
+      ebase[(size_t)t + 1] = ebase[(size_t)t] + cp[(size_t)t].ents.size();
+      sbase[(size_t)t + 1] = sbase[(size_t)t] + cp[(size_t)t].blk_ent_start.size();
+      nblk_reduced += cp[(size_t)t].nblk_reduced; nvarpts += cp[(size_t)t].nvarpts;
     }
-    close_chunk(h->np_chunked);
+    if (ebase[(size_t)cparts] > (size_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "too many Schur pairs for 32-bit entry offsets");
+    blk_desc.resize(bbase[(size_t)cparts]); ents.resize(ebase[(size_t)cparts]); blk_ent_start.resize(sbase[(size_t)cparts]);
+    run_parts(cparts, [&](int t, int nparts) {
+      const ChunkPart& C = cp[(size_t)t];
+      std::copy(C.blk_desc.begin(), C.blk_desc.end(), blk_desc.begin() + (std::ptrdiff_t)bbase[(size_t)t]);
+      std::copy(C.ents.begin(), C.ents.end(), ents.begin() + (std::ptrdiff_t)ebase[(size_t)t]);
+      std::copy(C.blk_ent_start.begin(), C.blk_ent_start.end(), blk_ent_start.begin() + (std::ptrdiff_t)sbase[(size_t)t]);
+      for (int c = (int)((int64_t)nch * t / nparts); c < (int)((int64_t)nch * (t + 1) / nparts); ++c) {
+        chunks[(size_t)c].blk0 += (int32_t)bbase[(size_t)t];
+        chunks[(size_t)c].ent0 += (int32_t)ebase[(size_t)t];
+      }
+    });
   }
+  lap("concatenate pair tables");
   if (ents.size() > (size_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "too many Schur pairs for 32-bit entry offsets");
   h->nchunks = (int)chunks.size();
-  h->nrec = (int64_t)rec_cam.size();
-  h->nblocks_reduced = nblk_reduced;
   std::vector<LongHdr> lhdr;
   int64_t wl_rows = 0;
-  for (int64_t k = h->np_chunked; k < h->np_chunked + n_long; ++k) {
-    const int p = order[k];
-    LongHdr L{};
-    L.rec0 = (int32_t)rec_cam.size(); L.pt = (int32_t)k; L.w0 = wl_rows;
-    pt_rec_start[k] = L.rec0;
-    int kv = 0;
-    for (int64_t r = prec[p]; r < prec[p + 1]; ++r) {
-      const Rec& R = recs[r];
-      if (R.slot >= 0) ++kv;
-      rec_cam.push_back(R.cam); rec_pt.push_back((int32_t)k);
-      rec_meta.push_back((R.slot >= 0 ? 0u : kLcamConst) | R.flags);
-      rec_xy.push_back(R.u); rec_xy.push_back(R.v); rec_d.push_back(R.d); rec_m.push_back(R.m); rec_a.push_back(R.a);
-      nblk_reduced += ((R.flags & kRecHasReproj) ? 1 : 0) + ((R.flags & kRecHasDepth) ? 1 : 0);
+  {
+    size_t w = h->np_chunked > 0 ? (size_t)(pt_rec_start[(size_t)h->np_chunked - 1] + (prec[order[h->np_chunked - 1] + 1] - prec[order[h->np_chunked - 1]])) : 0;
+    for (int64_t k = h->np_chunked; k < h->np_chunked + n_long; ++k) {
+      const int p = order[k];
+      LongHdr L{};
+      L.rec0 = (int32_t)w; L.pt = (int32_t)k; L.w0 = wl_rows;
+      pt_rec_start[k] = L.rec0;
+      int kv = 0;
+      for (int64_t r = prec[p]; r < prec[p + 1]; ++r, ++w) {
+        const Rec& R = recs[r];
+        if (R.slot >= 0) ++kv;
+        rec_cam[w] = R.cam; rec_pt[w] = (int32_t)k;
+        rec_meta[w] = (R.slot >= 0 ? 0u : kLcamConst) | R.flags;
+        rec_xy[2 * w] = R.u; rec_xy[2 * w + 1] = R.v; rec_d[w] = R.d; rec_m[w] = R.m; rec_a[w] = R.a;
+        nblk_reduced += ((R.flags & kRecHasReproj) ? 1 : 0) + ((R.flags & kRecHasDepth) ? 1 : 0);
+      }
+      L.nrec = (int32_t)w - L.rec0;
+      L.kv = P->pt_const[p] ? 0 : kv;
+      if (!P->pt_const[p]) { pt_kv[k] = (uint16_t)std::min(kv, 0xfffe); nvarpts += 1; }
+      wl_rows += kv;
+      lhdr.push_back(L);
     }
-    L.nrec = (int32_t)rec_cam.size() - L.rec0;
-    L.kv = P->pt_const[p] ? 0 : kv;
-    if (!P->pt_const[p]) { pt_kv[k] = (uint16_t)std::min(kv, 0xfffe); nvarpts += 1; }
-    wl_rows += kv;
-    lhdr.push_back(L);
   }
   h->nlong = (int)lhdr.size();
-  h->nrec = (int64_t)rec_cam.size();
+  h->nrec = nrec_total;
   h->nblocks_reduced = nblk_reduced;
-  if (rec_cam.size() > (size_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "more than 2^31 records on one device");
   for (int64_t k = h->np_chunked + n_long; k <= h->np; ++k) pt_rec_start[k] = (int32_t)h->nrec;
   {
     double tot[3] = {(double)h->nblocks_total, (double)nblk_reduced, nvarpts};
@@ -505,6 +772,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_fx_m, fx_m))) return rc;
   if ((rc = dev_upload(&h->d_fx_a, fx_a))) return rc;
 
+  if ((rc = drain_uploads())) return rc;
   lap("upload tables");
   const size_t ncs = (size_t)std::max(nc, 1), nps = (size_t)std::max<int64_t>(h->np, 1);
   for (double** p : {&h->d_q, &h->d_q2, &h->d_q0}) if ((rc = dev_alloc(p, ncs * 4))) return rc;
@@ -539,20 +807,37 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
 
 static int upload_state(mpsfm_ba_handle* h, const mpsfm_ba_state* st, bool as_initial) {
   if (!st || (h->nc > 0 && (!st->cam_quat_xyzw || !st->cam_t)) || (h->np > 0 && !st->pts)) return fail(MPSFM_EINVAL, "state is NULL");
-  HIP_TRY(hipMemcpyAsync(h->d_q, st->cam_quat_xyzw, sizeof(double) * 4 * h->nc, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_t, st->cam_t, sizeof(double) * 3 * h->nc, hipMemcpyHostToDevice, h->stream));
-  std::vector<double> sorted((size_t)h->np * 3);
-  for (int64_t k = 0; k < h->np; ++k) {
-    const double* s = st->pts + 3 * (size_t)h->perm[k];
-    sorted[3 * k] = s[0]; sorted[3 * k + 1] = s[1]; sorted[3 * k + 2] = s[2];
-  }
-  if (h->np > 0) HIP_TRY(hipMemcpyAsync(h->d_pts, sorted.data(), sizeof(double) * 3 * h->np, hipMemcpyHostToDevice, h->stream));
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (h->opt.verbose < 2) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[mpsfm_ba] state: %-28s %8.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  // caller memory is pageable: staged copies (see Stager).  The handle's stream is idle between solves.
   HIP_TRY(hipStreamSynchronize(h->stream));
+  lap("stream idle");
+  if (h->nc > 0) {
+    if (int rc = staged_h2d(h->d_q, st->cam_quat_xyzw, sizeof(double) * 4 * h->nc)) return rc;
+    if (int rc = staged_h2d(h->d_t, st->cam_t, sizeof(double) * 3 * h->nc)) return rc;
+  }
+  lap("pose copies");
+  std::vector<double> sorted((size_t)h->np * 3);
+  parallel_ranges(h->np, 16384, [&](int64_t k0, int64_t k1) {
+    for (int64_t k = k0; k < k1; ++k) {
+      const double* s = st->pts + 3 * (size_t)h->perm[(size_t)k];
+      sorted[3 * (size_t)k] = s[0]; sorted[3 * (size_t)k + 1] = s[1]; sorted[3 * (size_t)k + 2] = s[2];
+    }
+  });
+  lap("permute landmarks");
+  if (h->np > 0) if (int rc = staged_h2d(h->d_pts, sorted.data(), sizeof(double) * 3 * h->np)) return rc;
+  lap("landmark copy");
   if (as_initial) {
     HIP_TRY(hipMemcpyAsync(h->d_q0, h->d_q, sizeof(double) * 4 * h->nc, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_t0, h->d_t, sizeof(double) * 3 * h->nc, hipMemcpyDeviceToDevice, h->stream));
     if (h->np > 0) HIP_TRY(hipMemcpyAsync(h->d_pts0, h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    lap("keep initial state");
   }
   h->scales_ready = false;
   return 0;
@@ -795,15 +1080,33 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
 static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, const mpsfm_ba_options* o, mpsfm_ba_handle** out) {
   if (!out) return fail(MPSFM_EINVAL, "out is NULL");
   *out = nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [&](const char* what) {
+    if (o && o->verbose >= 2)
+      std::fprintf(stderr, "[mpsfm_ba] create: %-27s %8.2f ms (cumulative)\n", what,
+                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   if (int rc = check_problem(P)) return rc;
   if (!o) return fail(MPSFM_EINVAL, "options is NULL");
+  since("check_problem");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MPSFM_ENODEVICE, "no HIP device visible: libmpsfm_hip has no CPU fallback");
   if (o->device < 0 || o->device >= ndev) return fail(MPSFM_EINVAL, "device ordinal out of range");
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, o->device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(MPSFM_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  {
+    // the architecture of a device does not change: query it once per process and device
+    static std::mutex mu;
+    static std::vector<std::string> arch;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)arch.size() < ndev) arch.resize((size_t)ndev);
+    if (arch[(size_t)o->device].empty()) {
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, o->device));
+      arch[(size_t)o->device] = prop.gcnArchName;
+    }
+    if (std::strncmp(arch[(size_t)o->device].c_str(), "gfx950", 6) != 0)
+      return fail(MPSFM_ENODEVICE, std::string("device is ") + arch[(size_t)o->device] + ", this library is built for gfx950 only");
+  }
+  since("device check");
   HIP_TRY(hipSetDevice(o->device));
   mpsfm_ba_handle* h = new mpsfm_ba_handle();
   h->device = o->device; h->opt = *o;
@@ -813,7 +1116,9 @@ static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, cons
     h->own_stream = true;
   }
   int rc = build(h, P, st);
+  since("build");
   if (rc == 0 && st) rc = upload_state(h, st, true);
+  since("upload_state");
   if (rc) { free_handle(h); return rc; }
   *out = h;
   return 0;
@@ -884,11 +1189,13 @@ int mpsfm_ba_solve_resident(mpsfm_ba_handle* h, mpsfm_ba_summary* summary) {
 int mpsfm_ba_get_state(mpsfm_ba_handle* h, mpsfm_ba_state* st) {
   if (!h || !st) return fail(MPSFM_EINVAL, "handle or state is NULL");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpyAsync(st->cam_quat_xyzw, h->d_q, sizeof(double) * 4 * h->nc, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(st->cam_t, h->d_t, sizeof(double) * 3 * h->nc, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));  // then blocking copies: pageable destinations (see upload_state)
+  if (h->nc > 0) {
+    HIP_TRY(hipMemcpy(st->cam_quat_xyzw, h->d_q, sizeof(double) * 4 * h->nc, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st->cam_t, h->d_t, sizeof(double) * 3 * h->nc, hipMemcpyDeviceToHost));
+  }
   std::vector<double> sorted((size_t)h->np * 3);
-  if (h->np > 0) HIP_TRY(hipMemcpyAsync(sorted.data(), h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->np > 0) HIP_TRY(hipMemcpy(sorted.data(), h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToHost));
   for (int64_t k = 0; k < h->np; ++k) {
     double* d = st->pts + 3 * (size_t)h->perm[k];
     d[0] = sorted[3 * k]; d[1] = sorted[3 * k + 1]; d[2] = sorted[3 * k + 2];
@@ -902,11 +1209,22 @@ int mpsfm_ba_solve(const mpsfm_ba_problem* problem, mpsfm_ba_state* state, const
                    mpsfm_ba_summary* summary) {
   if (!state || !summary) return fail(MPSFM_EINVAL, "state or summary is NULL");
   mpsfm_ba_handle* h = nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!options || options->verbose < 2) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[mpsfm_ba] one-shot: %-25s %8.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   int rc = create_impl(problem, state, options, &h);
   if (rc) return rc;
+  lap("create");
   rc = solve_impl(h, summary);
+  lap("solve");
   if (rc == 0) rc = mpsfm_ba_get_state(h, state);
+  lap("get_state");
   free_handle(h);
+  lap("destroy");
   return rc;
 }
 

@@ -11,4 +11,5 @@ for i in range(3):
     h.options.verbose = 0
     h.close()
     print(f"create {1e3*(t1-t0):.1f} ms", flush=True)
-t0 = time.perf_counter(); s = capi.ba_solve(base.copy()); print(f"one-shot {1e3*(time.perf_counter()-t0):.1f} ms, iters {s['num_iterations']}")
+p = base.copy(); t0 = time.perf_counter(); s = capi.ba_solve(p); print(f"one-shot {1e3*(time.perf_counter()-t0):.1f} ms")
+p = base.copy(); t0 = time.perf_counter(); s = capi.ba_solve(p, capi.default_options(verbose=2)); print(f"one-shot {1e3*(time.perf_counter()-t0):.1f} ms, iters {s['num_iterations']}")
