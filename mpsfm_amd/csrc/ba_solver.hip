@@ -1041,7 +1041,21 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
       if (invalid_run >= o.max_num_consecutive_invalid_steps) term = MPSFM_TERM_INVALID_STEPS;
       radius /= decrease_factor; decrease_factor *= 2.0;
       trace(cur_cost + fixed, radius, 0);
-      if (o.verbose > 0) std::fprintf(stderr, "[mpsfm_ba] it %3d invalid step (chol_fail=%d mcc=%.3e) radius %.3e\n", iter, h_fail, mcc, radius);
+      if (o.verbose > 0) {
+        std::fprintf(stderr, "[mpsfm_ba] it %3d invalid step (chol_fail=%d mcc=%.3e) radius %.3e\n", iter, h_fail, mcc, radius);
+        // diagnostics: which intermediate holds the non-finite value
+        std::vector<double> yc((size_t)std::max(h->n, 1)), red((size_t)h->red_count);
+        (void)hipMemcpy(yc.data(), h->d_yc, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(red.data(), h->d_red, sizeof(double) * (size_t)h->red_count, hipMemcpyDeviceToHost);
+        int64_t bad_y = 0, bad_S = 0, bad_rest = 0;
+        for (int i = 0; i < h->n; ++i) bad_y += !std::isfinite(yc[(size_t)i]);
+        for (int64_t i = 0; i < h->sblk_count; ++i) bad_S += !std::isfinite(red[(size_t)i]);
+        for (int64_t i = h->sblk_count; i < h->red_count; ++i) bad_rest += !std::isfinite(red[(size_t)i]);
+        std::fprintf(stderr, "[mpsfm_ba]     non-finite: y_c %lld of %d, S %lld, g/w/diagU/scalars %lld; scalars:", (long long)bad_y, h->n,
+                     (long long)bad_S, (long long)bad_rest);
+        for (int i = 0; i < U_COUNT; ++i) std::fprintf(stderr, " %.3e", sc[i]);
+        std::fprintf(stderr, "\n");
+      }
       continue;
     }
     invalid_run = 0;

@@ -357,12 +357,10 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
     bool ok = true;
     if (!(dbg & 1)) ok = potrf_tile(s_T, lane, s_inv, s_col, s_Lt, &s_ready);
     else if (lane == 0) __hip_atomic_store(&s_ready, kTile, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (diag) {
-      for (int e = lane; e < kTileElems; e += 64) {
-        const int r = e >> 5, c = e & 31;
-        C[e] = (c <= r) ? s_Lt[c * kTile + r] : 0.0;
-      }
-    }
+    // The factored diagonal tile is NOT written back over A(tk,tk): every workgroup of this panel column
+    // loads A(tk,tk) at its start, and one that is scheduled late (a busy GPU) would otherwise find L there
+    // instead of the matrix.  Nothing reads L(tk,tk) from memory afterwards — the back substitution uses the
+    // stored L^-T of the diagonal tiles.
     if (diag && !ok && lane == 0) atomicExch(fail, 1);
   } else {
     if (diag) {

@@ -10,6 +10,7 @@ dense solve is replicated.  The exchange is injected into the solver through the
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -66,6 +67,7 @@ def make_torch_allreduce(group=None):
     import torch.distributed as dist
 
     backend = dist.get_backend(group)
+    paranoid = os.environ.get("MPSFM_DIST_SYNC") == "1"  # debugging aid: device-wide sync around every collective
 
     def _cb(user, buf, count, on_device, stream):
         try:
@@ -74,8 +76,18 @@ def make_torch_allreduce(group=None):
                 return 0
             ptr = C.addressof(buf.contents)
             if on_device:
-                t = torch.as_tensor(_DevView(ptr, count), device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                # The buffer is produced and consumed on the solver's HIP stream, which is NOT torch's
+                # current stream in general (the library creates its own when options.stream is 0).  Make
+                # it current for the collective: RCCL's stream then waits for the kernels queued before
+                # the call, and work.wait() makes the solver's stream wait for the collective.
+                s = torch.cuda.ExternalStream(int(stream)) if stream else torch.cuda.current_stream()
+                if paranoid:
+                    torch.cuda.synchronize()
+                with torch.cuda.stream(s):
+                    t = torch.as_tensor(_DevView(ptr, count), device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                if paranoid:
+                    torch.cuda.synchronize()
             else:
                 a = np.ctypeslib.as_array(buf, shape=(count,))
                 t = torch.from_numpy(a)

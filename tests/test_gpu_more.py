@@ -338,3 +338,43 @@ def test_rccl_hook_single_rank():
     s = capi.ba_solve(ref)
     assert d["solve"]["final_cost"] == pytest.approx(s["final_cost"], rel=1e-9)
     assert d["solve"]["lm_iterations"] == s["num_iterations"]
+
+
+@pytest.mark.timeout(600)
+def test_two_process_sharded_solve_on_one_gpu(tmp_path):
+    """Two OS processes, one landmark shard each, both on cuda:0; the reduced system is summed across them on
+    the DEVICE buffers through mpsfm_amd.dist.make_torch_allreduce (gloo here: RCCL does not allow two ranks
+    on one GPU).  The library runs on a stream of its own, so this fails if the hook does not order the
+    collective with that stream.  Must reproduce the single-process trajectory."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    seed, world = 77, 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_gpu_worker.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), str(seed)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=500) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    res = [json.load(open(tmp_path / f"r{r}.json")) for r in range(world)]
+    if not all(r["supported"] for r in res):
+        pytest.skip("this torch build cannot all-reduce device tensors with gloo")
+    ref, _ = make_scene(12, 6000, True, seed=seed)
+    s = capi.ba_solve(ref)
+    for r, o in enumerate(res):
+        assert o["iters"] == s["num_iterations"] and o["nblocks"] == s["num_residual_blocks"]
+        assert o["initial_cost"] == pytest.approx(s["initial_cost"], rel=1e-12)
+        assert o["final_cost"] == pytest.approx(s["final_cost"], rel=1e-9)
+        np.testing.assert_allclose(o["trace"], s["trace_cost"], rtol=1e-9)
+        st = np.load(tmp_path / f"state{r}.npz")
+        np.testing.assert_allclose(st["cam_t"], ref.cam_t, atol=1e-7)
+        np.testing.assert_allclose(st["pts"], ref.pts[o["lo"]:o["hi"]], atol=1e-6)
