@@ -47,6 +47,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal aids (several ranks on ONE GPU, where RCCL refuses duplicate devices): MPSFM_BENCH_DEVICE pins the
+    # device ordinal, MPSFM_BENCH_BACKEND=gloo sums the device buffers through gloo.  Not used by the driver.
+    local_rank = int(os.environ.get("MPSFM_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MPSFM_BENCH_BACKEND", "nccl")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -62,7 +66,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     prob, _ = make_config(args.config, seed=0, shard=rank)
     opts = capi.default_options(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
@@ -164,7 +171,7 @@ def main():
         "roofline_other": other,
     }
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # CPU baseline and side measurements at N=1 only
         out["cpu_baseline"] = cpu_baseline(args, last)
         try:
             out["extras"] = {"integration_290x387": integration_leg(local_rank)}
