@@ -270,6 +270,14 @@ typedef struct mpsfm_int_summary {
 int mpsfm_integrate_depth(const mpsfm_int_problem* problem, int32_t device, double* depth_out /* [H*W] */,
                           mpsfm_int_summary* summary);
 
+/* The same solve for a batch of images in ONE sequence of launches (what MpsfmMapper.integrate_bundle loops
+ * over, reference mapper/base.py:619-631): kernels run on a (pixels, image) grid, every image keeps its own
+ * IRLS / CG state and stops on its own tests, so the results are identical to n single calls while the
+ * launch and synchronisation latency is paid once.  All images must share H, W and the configuration
+ * scalars (MPSFM_EINVAL otherwise); summaries[i].ms is the device time of the whole batch. */
+int mpsfm_integrate_depth_batch(int32_t n_images, const mpsfm_int_problem* problems /* [n] */, int32_t device,
+                                double* const* depth_out /* [n] pointers to H*W */, mpsfm_int_summary* summaries /* [n] */);
+
 /* ---- row f4: uncertainty propagation through the integration (reference
  *    mpsfm/sfm/scene/image/integration.py:51-79 `IntegrationUncertainty`, :522-574 `calculate_hessian`,
  *    :576-616 `calculate_int_covs_at_points / _at_kps`).  The "Hessian" is the matrix of calc_Amat built at

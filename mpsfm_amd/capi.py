@@ -22,7 +22,8 @@ EXPORTS = [
     "mpsfm_ba_solve_resident", "mpsfm_ba_get_state", "mpsfm_ba_destroy", "mpsfm_ba_eval_cost",
     "mpsfm_ba_sweep_once", "mpsfm_ba_get_reduced_system", "mpsfm_ba_reduced_dim",
     "mpsfm_ba_get_dense_solution", "mpsfm_ba_dense_solve_once", "mpsfm_point_covs",
-    "mpsfm_triangulate_tracks", "mpsfm_filter_tracks", "mpsfm_integrate_depth", "mpsfm_integration_variances",
+    "mpsfm_triangulate_tracks", "mpsfm_filter_tracks", "mpsfm_integrate_depth", "mpsfm_integrate_depth_batch",
+    "mpsfm_integration_variances",
 ]
 
 _lib = None
@@ -268,6 +269,44 @@ def integrate_depth(depth_prior, depth_uncertainty, valid, normals, normals_var,
                    energy_final=S.energy_final, cg_iters=[S.cg_iters[i] for i in range(n)],
                    energies=[S.energies[i] for i in range(n + 1)], ms=S.ms)
     return (out if S.changed else None), summary, wu, wv
+
+
+def _int_summary_dict(S):
+    n = S.irls_iterations
+    return dict(changed=bool(S.changed), irls_iterations=n, cg_iterations_total=S.cg_iterations_total,
+                integrated=bool(S.integrated_out), energy_old=S.energy_old_out, energy_initial=S.energy_initial,
+                energy_final=S.energy_final, cg_iters=[S.cg_iters[i] for i in range(n)],
+                energies=[S.energies[i] for i in range(n + 1)], ms=S.ms)
+
+
+def integrate_depth_batch(items, conf=None, device=0):
+    """mpsfm_integrate_depth_batch.  `items`: list of dicts with the arguments of `integrate_depth`
+    (depth_prior, depth_uncertainty, valid, normals, normals_var, depth_init, K, kps, depth3d, zvars3d and
+    optionally init, integrated, energy_old, wu, wv); all maps of one size.  Returns a list of
+    (depth map or None, summary dict, wu, wv) in the same order."""
+    from .problem import CIntProblem, CIntSummary
+
+    n = len(items)
+    if n == 0:
+        return []
+    Ps = (CIntProblem * n)()
+    Ss = (CIntSummary * n)()
+    keep, outs, wus, wvs = [], [], [], []
+    for i, it in enumerate(items):
+        P, k, (H, W), wu, wv = _int_problem(it["depth_prior"], it["depth_uncertainty"], it["valid"], it["normals"], it["normals_var"],
+                                            it["depth_init"], it["K"], it["kps"], it["depth3d"], it["zvars3d"], conf,
+                                            it.get("init", True), it.get("integrated", False), it.get("energy_old", 0.0),
+                                            it.get("wu"), it.get("wv"))
+        Ps[i] = P
+        keep.append(k)
+        outs.append(np.zeros((H, W)))
+        wus.append(wu)
+        wvs.append(wv)
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    L = lib()
+    L.mpsfm_integrate_depth_batch.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    _check(L.mpsfm_integrate_depth_batch(n, C.byref(Ps), device, C.byref(ptrs), C.byref(Ss)))
+    return [((outs[i] if Ss[i].changed else None), _int_summary_dict(Ss[i]), wus[i], wvs[i]) for i in range(n)]
 
 
 def integration_variances(depth_prior, depth_uncertainty, valid, normals, normals_var, depth_checkpoint, K, query_xy,

@@ -24,16 +24,31 @@ static int ifail(int code, const std::string& m) { g_err = m; return code; }
 
 constexpr int kIT = 256;  // threads per workgroup
 
+// A batch of B images of one size: every per-pixel array is [B][N] (w4: [B][4][N]); part is [B][G][8],
+// state [B][8].  Kernels are launched on a (G, B) grid; blockIdx.y picks the image.
 struct IntDev {
-  int H, W, N;
+  int H, W, N, B, G;
   // per pixel
   double *dp, *zp, *z, *nx, *ny, *nzu, *nzv, *Nu, *Nv;   // prepared inputs
   double *wu, *wv, *w4;                                   // w4: [4][N] wu_plus, wu_minus, wv_plus, wv_minus
   double *d, *cr, *cd, *b, *minv, *spd, *spb;             // system: diagonal, right/down coupling, rhs, 1/clip(diag)
   double *r, *zz, *p0, *p1, *q;                           // CG vectors (p double-buffered)
-  double *part;                                           // [grid][4] partial sums
+  double *part;                                           // [grid][8] partial sums
   double *state;                                          // [8]: rho_prev, atol^2, done, iterations, alpha-denominator ...
+  const int32_t* act;                                     // [B] 1: the image takes part in this launch
 };
+
+// the view of image b: all pointers advanced to its slice
+__device__ __forceinline__ IntDev int_image(IntDev D, int b) {
+  const size_t o = (size_t)b * (size_t)D.N;
+  D.dp += o; D.zp += o; D.z += o; D.nx += o; D.ny += o; D.nzu += o; D.nzv += o; D.Nu += o; D.Nv += o;
+  D.wu += o; D.wv += o; D.w4 += 4 * o;
+  D.d += o; D.cr += o; D.cd += o; D.b += o; D.minv += o; D.spd += o; D.spb += o;
+  D.r += o; D.zz += o; D.p0 += o; D.p1 += o; D.q += o;
+  D.part += (size_t)b * (size_t)D.G * 8;
+  D.state += (size_t)b * 8;
+  return D;
+}
 
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
@@ -83,34 +98,41 @@ __device__ __forceinline__ void sum_partials(const double* part, int nblocks, in
 
 struct PrepArgs {
   int H, W;
-  const double *depth_prior, *depth_unc, *normals, *nvar, *depth_init;
-  const uint8_t* valid;
-  double fx, fy, cx, cy, large, dmult, nmult;
+  const double *depth_prior, *depth_unc, *normals, *nvar, *depth_init;  // [B][N] (normals, nvar: [B][N][3])
+  const uint8_t* valid;                                                  // [B][N]
+  const double* K;                                                       // [B][4] fx fy cx cy in map pixels
+  double large, dmult, nmult;
 };
 
 // process_depth_prior / process_normals_prior / load_depth_checkpoint / init_int_vars (nz_u, nz_v, precisions)
-__global__ __launch_bounds__(kIT) void k_int_prepare(PrepArgs a, IntDev D) {
+__global__ __launch_bounds__(kIT) void k_int_prepare(PrepArgs a, IntDev Dall) {
+  const int bimg = blockIdx.y;
+  if (!Dall.act[bimg]) return;
+  const IntDev D = int_image(Dall, bimg);
   const int p = blockIdx.x * kIT + threadIdx.x;
   if (p >= D.N) return;
+  const size_t o = (size_t)bimg * (size_t)D.N;
+  const double fx = a.K[4 * bimg], fy = a.K[4 * bimg + 1], cx = a.K[4 * bimg + 2], cy = a.K[4 * bimg + 3];
+  const double* nrm = a.normals + 3 * o; const double* nvr = a.nvar + 3 * o;
   const int row = p / a.W, col = p - row * a.W;
-  const double dpr = a.depth_prior[p];
-  D.dp[p] = a.dmult * (1.0 / (a.depth_unc[p] + 1e-6)) * dpr * dpr;
+  const double dpr = a.depth_prior[o + p];
+  D.dp[p] = a.dmult * (1.0 / (a.depth_unc[o + p] + 1e-6)) * dpr * dpr;
   D.zp[p] = log(dpr);
-  D.z[p] = log(a.depth_init[p]);
-  const double nx = a.normals[3 * p + 1], ny = a.normals[3 * p], nz = -a.normals[3 * p + 2];
-  const bool ok = a.valid[p] != 0;
+  D.z[p] = log(a.depth_init[o + p]);
+  const double nx = nrm[3 * p + 1], ny = nrm[3 * p], nz = -nrm[3 * p + 2];
+  const bool ok = a.valid[o + p] != 0;
   const double m = 1.0 / a.nmult;
-  const double Vnx = m * (ok ? a.nvar[3 * p + 1] : a.large), Vny = m * (ok ? a.nvar[3 * p] : a.large),
-               Vnz = m * (ok ? a.nvar[3 * p + 2] : a.large);
-  const double uu = (double)(a.H - 1 - row) - a.cx, vv = (double)col - a.cy;
+  const double Vnx = m * (ok ? nvr[3 * p + 1] : a.large), Vny = m * (ok ? nvr[3 * p] : a.large),
+               Vnz = m * (ok ? nvr[3 * p + 2] : a.large);
+  const double uu = (double)(a.H - 1 - row) - cx, vv = (double)col - cy;
   const double base = uu * nx + vv * ny;
-  const double nzu = base + a.fx * nz, nzv = base + a.fy * nz;
+  const double nzu = base + fx * nz, nzv = base + fy * nz;
   const double Du = -nx / nzu, Dv = -ny / nzv;
   D.nx[p] = nx; D.ny[p] = ny; D.nzu[p] = nzu; D.nzv[p] = nzv;
   const double a1 = uu * Du + 1.0, a2 = vv * Du;
-  D.Nu[p] = 1.0 / (Vnx * (a1 * a1) + Vny * (a2 * a2) + a.fx * a.fx * Vnz * Du * Du);
+  D.Nu[p] = 1.0 / (Vnx * (a1 * a1) + Vny * (a2 * a2) + fx * fx * Vnz * Du * Du);
   const double b1 = uu * Dv, b2 = vv * Dv + 1.0;
-  D.Nv[p] = 1.0 / (Vnx * (b1 * b1) + Vny * (b2 * b2) + a.fy * a.fy * Vnz * Dv * Dv);
+  D.Nv[p] = 1.0 / (Vnx * (b1 * b1) + Vny * (b2 * b2) + fy * fy * Vnz * Dv * Dv);
 }
 
 __device__ __forceinline__ double sigmoid_k(double x, double k) {
@@ -121,7 +143,10 @@ __device__ __forceinline__ double sigmoid_k(double x, double k) {
 
 // update_W (unless the cached weights are kept), calc_Wpm and the energy of calc_energy.
 // partial columns: 0 normal terms, 1 depth-prior term
-__global__ __launch_bounds__(kIT) void k_int_weights(IntDev D, double kk, double lambda1, int keep_w) {
+__global__ __launch_bounds__(kIT) void k_int_weights(IntDev Dall, double kk, double lambda1, const int32_t* keep_w_img) {
+  if (!Dall.act[blockIdx.y]) return;
+  const IntDev D = int_image(Dall, blockIdx.y);
+  const int keep_w = keep_w_img[blockIdx.y];
   const int p = blockIdx.x * kIT + threadIdx.x;
   double e[2] = {0.0, 0.0};
   if (p < D.N) {
@@ -149,23 +174,29 @@ __global__ __launch_bounds__(kIT) void k_int_weights(IntDev D, double kk, double
   block_partials<2>(e, D.part);
 }
 
-// sparse depth term of the energy (all entries, duplicates included — calc_energy :163-164)
-__global__ __launch_bounds__(kIT) void k_int_sparse_energy(int n, const int32_t* ids, const double* prec, const double* sdepth,
-                                                           const double* z, double lambda2, double* out) {
+// sparse depth term of the energy (all entries, duplicates included — calc_energy :163-164); one
+// workgroup per image, entries of image b are [off[b], off[b+1])
+__global__ __launch_bounds__(kIT) void k_int_sparse_energy(IntDev Dall, const int32_t* off, const int32_t* ids, const double* prec,
+                                                           const double* sdepth, double lambda2, double* out) {
+  const int bimg = blockIdx.x;
+  if (!Dall.act[bimg]) return;
+  const double* z = Dall.z + (size_t)bimg * (size_t)Dall.N;
   __shared__ double s[kIT / 64];
   double e = 0.0;
-  for (int i = threadIdx.x; i < n; i += kIT) {
+  for (int i = off[bimg] + (int)threadIdx.x; i < off[bimg + 1]; i += kIT) {
     const double dz = sdepth[i] - z[ids[i]];
     e += lambda2 * prec[i] * dz * dz;
   }
   e = wsum(e);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = e;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = (s[0] + s[1]) + (s[2] + s[3]);
+  if (threadIdx.x == 0) out[bimg] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 // calc_Amat (:167-234) and the right-hand side (:450-459) in stencil form
-__global__ __launch_bounds__(kIT) void k_int_system(IntDev D, double lambda1) {
+__global__ __launch_bounds__(kIT) void k_int_system(IntDev Dall, double lambda1) {
+  if (!Dall.act[blockIdx.y]) return;
+  const IntDev D = int_image(Dall, blockIdx.y);
   const int p = blockIdx.x * kIT + threadIdx.x;
   if (p >= D.N) return;
   const int W = D.W, H = D.H, N = D.N;
@@ -205,7 +236,9 @@ __device__ __forceinline__ double stencil_apply(const IntDev& D, const double* x
 }
 
 // r = b - A z, zz = M r; partials: 0 (r,zz), 1 (r,r), 2 (b,b)
-__global__ __launch_bounds__(kIT) void k_cg_init(IntDev D) {
+__global__ __launch_bounds__(kIT) void k_cg_init(IntDev Dall) {
+  if (!Dall.act[blockIdx.y]) return;
+  const IntDev D = int_image(Dall, blockIdx.y);
   const int p = blockIdx.x * kIT + threadIdx.x;
   double v[3] = {0.0, 0.0, 0.0};
   if (p < D.N) {
@@ -221,7 +254,9 @@ __global__ __launch_bounds__(kIT) void k_cg_init(IntDev D) {
 // state: [0] rho_prev, [1] atol^2, [2] done, [3] iterations, [4] rho_cur (for the update kernel)
 // Direction + matvec: p_new = zz + beta p_old, q = A p_new; partial 0: (p_new, q).
 // Stops (and marks done) when |r| < atol, like scipy.sparse.linalg.cg's loop head.
-__global__ __launch_bounds__(kIT) void k_cg_dir(IntDev D, int nblocks, int it, int first, double rtol) {
+__global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it, int first, double rtol) {
+  if (!Dall.act[blockIdx.y]) return;
+  const IntDev D = int_image(Dall, blockIdx.y);
   double sums[3];
   sum_partials<3>(D.part, nblocks, 0, sums);  // (r,zz), (r,r), (b,b)
   const double rho = sums[0], rr = sums[1];
@@ -260,7 +295,9 @@ __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev D, int nblocks, int it, i
 }
 
 // x += alpha p, r -= alpha q, zz = M r; partials 0 (r,zz), 1 (r,r)
-__global__ __launch_bounds__(kIT) void k_cg_update(IntDev D, int nblocks, int it) {
+__global__ __launch_bounds__(kIT) void k_cg_update(IntDev Dall, int nblocks, int it) {
+  if (!Dall.act[blockIdx.y]) return;
+  const IntDev D = int_image(Dall, blockIdx.y);
   double pq[1];
   sum_partials<1>(D.part, nblocks, 4, pq);
   const bool done = D.state[6] != 0.0;
@@ -286,9 +323,9 @@ __global__ __launch_bounds__(kIT) void k_cg_update(IntDev D, int nblocks, int it
   block_partials<2>(v, D.part);
 }
 
-__global__ __launch_bounds__(kIT) void k_int_exp(int N, const double* z, double* out) {
-  const int p = blockIdx.x * kIT + threadIdx.x;
-  if (p < N) out[p] = exp(z[p]);
+__global__ __launch_bounds__(kIT) void k_int_exp(size_t n, const double* z, double* out) {
+  const size_t p = (size_t)blockIdx.x * kIT + threadIdx.x;
+  if (p < n) out[p] = exp(z[p]);
 }
 
 struct IntPool {
@@ -309,22 +346,28 @@ struct StreamGuard {
 };
 
 // b = 1, x0 = 0: the system of IntegrationUncertainty (column sums of the inverse)
-__global__ __launch_bounds__(kIT) void k_int_unit_rhs(IntDev D) {
+__global__ __launch_bounds__(kIT) void k_int_unit_rhs(IntDev Dall) {
+  if (!Dall.act[blockIdx.y]) return;
+  const IntDev D = int_image(Dall, blockIdx.y);
   const int p = blockIdx.x * kIT + threadIdx.x;
   if (p < D.N) { D.b[p] = 1.0; D.z[p] = 0.0; }
 }
 
-// Host-side preparation shared by the two entry points: process_sparse_depth (+ the scale filter of
-// _integrate when asked), device buffers, uploads.
-struct IntSetup {
+// ---- host side ---------------------------------------------------------------------------------------
+// A batch of images of one size and one configuration, resident on the device.
+struct IntBatch {
   IntPool pool;
   IntDev D{};
-  int G = 0;
+  int B = 0, G = 0;
+  size_t N = 0;
+  std::vector<int32_t> sp_off;            // [B+1] sparse entries per image (after the scale filter)
   std::vector<int32_t> ids;
   std::vector<double> sprec, sdep;
-  int32_t* d_ids = nullptr;
-  double *d_sp = nullptr, *d_out = nullptr, *d_in = nullptr;
+  int32_t *d_ids = nullptr, *d_off = nullptr, *d_act = nullptr, *d_keep = nullptr;
+  double *d_sp = nullptr, *d_out = nullptr, *d_in = nullptr, *d_K = nullptr, *d_esp = nullptr;
   uint8_t* d_valid = nullptr;
+  std::vector<int32_t> act;               // host copy of the activity mask
+  std::vector<double> hpart, hstate, hesp;
 };
 
 static int int_check(const mpsfm_int_problem* P, int32_t device) {
@@ -342,89 +385,140 @@ static int int_check(const mpsfm_int_problem* P, int32_t device) {
   return 0;
 }
 
-static int int_setup(const mpsfm_int_problem* P, bool use_sparse, bool scale_filter, hipStream_t st, IntSetup& U) {
-  const int H = P->H, W = P->W, N = H * W;
+// images of a batch must agree in size and in every configuration value the kernels take as a scalar
+static bool int_same_config(const mpsfm_int_problem& a, const mpsfm_int_problem& b) {
+  return a.H == b.H && a.W == b.W && a.large_number == b.large_number && a.tol == b.tol && a.step_size == b.step_size &&
+         a.cg_tol == b.cg_tol && a.lambda1 == b.lambda1 && a.lambda2 == b.lambda2 && a.k == b.k &&
+         a.depth_magnitude_multiplier == b.depth_magnitude_multiplier && a.normals_magnitude_multiplier == b.normals_magnitude_multiplier &&
+         a.scale_filter_factor == b.scale_filter_factor && a.max_iter == b.max_iter && a.cg_max_iter == b.cg_max_iter &&
+         a.scale_filter == b.scale_filter;
+}
+
+// process_sparse_depth (+ the scale filter of _integrate when asked), device buffers, uploads
+static int int_setup(const mpsfm_int_problem* Ps, int B, bool use_sparse, bool scale_filter, hipStream_t st, IntBatch& U) {
+  const mpsfm_int_problem& P0 = Ps[0];
+  const int H = P0.H, W = P0.W;
+  const size_t N = (size_t)H * W;
+  U.B = B; U.N = N;
   // NumPy "last write wins" for duplicate pixels in A and b
-  std::vector<double> spd((size_t)N, 0.0), spb((size_t)N, 0.0);
-  for (int i = 0; use_sparse && i < P->n_sparse; ++i) {
-    const int id = P->sparse_y[i] * W + P->sparse_x[i];
-    const double d3 = P->sparse_depth3d[i];
-    if (scale_filter) {
-      const double div = std::exp(std::log(d3)) / std::exp(std::log(P->depth_prior[id]));
-      if (!(div < P->scale_filter_factor && div > 1.0 / P->scale_filter_factor)) continue;
+  std::vector<double> spd((size_t)B * N, 0.0), spb((size_t)B * N, 0.0), Kh((size_t)B * 4);
+  U.sp_off.assign((size_t)B + 1, 0);
+  for (int b = 0; b < B; ++b) {
+    const mpsfm_int_problem* P = &Ps[b];
+    const size_t first = U.ids.size();
+    for (int i = 0; use_sparse && i < P->n_sparse; ++i) {
+      const int id = P->sparse_y[i] * W + P->sparse_x[i];
+      const double d3 = P->sparse_depth3d[i];
+      if (scale_filter) {
+        const double div = std::exp(std::log(d3)) / std::exp(std::log(P->depth_prior[id]));
+        if (!(div < P->scale_filter_factor && div > 1.0 / P->scale_filter_factor)) continue;
+      }
+      U.ids.push_back(id); U.sprec.push_back((1.0 / P->sparse_zvar[i]) * d3 * d3); U.sdep.push_back(std::log(d3));
     }
-    U.ids.push_back(id); U.sprec.push_back((1.0 / P->sparse_zvar[i]) * d3 * d3); U.sdep.push_back(std::log(d3));
+    for (size_t i = first; i < U.ids.size(); ++i) {
+      spd[(size_t)b * N + U.ids[i]] = P->lambda2 * U.sprec[i];
+      spb[(size_t)b * N + U.ids[i]] = P->lambda2 * U.sprec[i] * U.sdep[i];
+    }
+    U.sp_off[(size_t)b + 1] = (int32_t)U.ids.size();
+    for (int k = 0; k < 4; ++k) Kh[(size_t)b * 4 + k] = P->K[k];
   }
   const auto& ids = U.ids;
-  for (size_t i = 0; i < ids.size(); ++i) { spd[ids[i]] = P->lambda2 * U.sprec[i]; spb[ids[i]] = P->lambda2 * U.sprec[i] * U.sdep[i]; }
-
   IntPool& pool = U.pool;
   IntDev& D = U.D;
-  const int G = U.G = (N + kIT - 1) / kIT;
-  D.H = H; D.W = W; D.N = N;
-  double* big = pool.get<double>((size_t)N * 28);
-  double* d_in = U.d_in = pool.get<double>((size_t)N * 9);
-  U.d_valid = pool.get<uint8_t>((size_t)N);
-  D.part = pool.get<double>((size_t)G * 8);
-  D.state = pool.get<double>(8);
+  const int G = U.G = (int)((N + kIT - 1) / kIT);
+  D.H = H; D.W = W; D.N = (int)N; D.B = B; D.G = G;
+  const size_t BN = (size_t)B * N;
+  double* big = pool.get<double>(BN * 28);
+  double* d_in = U.d_in = pool.get<double>(BN * 9);
+  U.d_valid = pool.get<uint8_t>(BN);
+  D.part = pool.get<double>((size_t)B * G * 8);
+  D.state = pool.get<double>((size_t)B * 8);
   U.d_ids = pool.get<int32_t>(ids.size());
+  U.d_off = pool.get<int32_t>((size_t)B + 1);
+  U.d_act = pool.get<int32_t>((size_t)B);
+  U.d_keep = pool.get<int32_t>((size_t)B);
   U.d_sp = pool.get<double>(ids.size() * 2 + 1);
-  U.d_out = pool.get<double>((size_t)N);
-  if (!big || !d_in || !U.d_valid || !D.part || !D.state || !U.d_ids || !U.d_sp || !U.d_out) return ifail(MPSFM_ENOMEM, "hipMalloc failed");
+  U.d_out = pool.get<double>(BN);
+  U.d_K = pool.get<double>((size_t)B * 4);
+  U.d_esp = pool.get<double>((size_t)B);
+  if (!big || !d_in || !U.d_valid || !D.part || !D.state || !U.d_ids || !U.d_off || !U.d_act || !U.d_keep || !U.d_sp || !U.d_out || !U.d_K || !U.d_esp)
+    return ifail(MPSFM_ENOMEM, "hipMalloc failed");
+  D.act = U.d_act;
   {
     double* c = big;
-    auto take = [&](size_t k) { double* r = c; c += k * (size_t)N; return r; };
+    auto take = [&](size_t k) { double* r = c; c += k * BN; return r; };
     D.dp = take(1); D.zp = take(1); D.z = take(1); D.nx = take(1); D.ny = take(1); D.nzu = take(1); D.nzv = take(1); D.Nu = take(1); D.Nv = take(1);
     D.wu = take(1); D.wv = take(1); D.w4 = take(4); D.d = take(1); D.cr = take(1); D.cd = take(1); D.b = take(1); D.minv = take(1);
     D.spd = take(1); D.spb = take(1); D.r = take(1); D.zz = take(1); D.p0 = take(1); D.p1 = take(1); D.q = take(1);
   }
-  INT_TRY(hipMemcpyAsync(d_in, P->depth_prior, sizeof(double) * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(d_in + N, P->depth_uncertainty, sizeof(double) * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(d_in + 2 * (size_t)N, P->depth_init, sizeof(double) * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(d_in + 3 * (size_t)N, P->normals, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(d_in + 6 * (size_t)N, P->normals_var, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(U.d_valid, P->valid, (size_t)N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(D.spd, spd.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(D.spb, spb.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemsetAsync(D.p0, 0, sizeof(double) * 2 * (size_t)N, st));
+  // inputs: [prior | unc | init] each [B][N], then normals [B][N][3], nvar [B][N][3]
+  for (int b = 0; b < B; ++b) {
+    const mpsfm_int_problem* P = &Ps[b];
+    INT_TRY(hipMemcpyAsync(d_in + (size_t)b * N, P->depth_prior, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(d_in + BN + (size_t)b * N, P->depth_uncertainty, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(d_in + 2 * BN + (size_t)b * N, P->depth_init, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(d_in + 3 * BN + (size_t)b * 3 * N, P->normals, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(d_in + 6 * BN + (size_t)b * 3 * N, P->normals_var, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
+    INT_TRY(hipMemcpyAsync(U.d_valid + (size_t)b * N, P->valid, N, hipMemcpyHostToDevice, st));
+  }
+  INT_TRY(hipMemcpyAsync(D.spd, spd.data(), sizeof(double) * BN, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(D.spb, spb.data(), sizeof(double) * BN, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(U.d_K, Kh.data(), sizeof(double) * 4 * B, hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemcpyAsync(U.d_off, U.sp_off.data(), sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, st));
+  INT_TRY(hipMemsetAsync(D.p0, 0, sizeof(double) * 2 * BN, st));
   if (!ids.empty()) {
     INT_TRY(hipMemcpyAsync(U.d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, st));
     INT_TRY(hipMemcpyAsync(U.d_sp, U.sprec.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
     INT_TRY(hipMemcpyAsync(U.d_sp + ids.size(), U.sdep.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
   }
-  // spd / spb are host vectors that die with this frame: the copies above must have left them
+  U.act.assign((size_t)B, 1);
+  INT_TRY(hipMemcpyAsync(U.d_act, U.act.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
+  // spd / spb / Kh are host vectors that die with this frame: the copies above must have left them
   INT_TRY(hipStreamSynchronize(st));
+  U.hpart.resize((size_t)B * G * 8); U.hstate.resize((size_t)B * 8); U.hesp.resize((size_t)B);
   return 0;
 }
 
-static void int_launch_prepare(const mpsfm_int_problem* P, IntSetup& U, hipStream_t st) {
-  const size_t N = (size_t)U.D.N;
-  PrepArgs pa{P->H, P->W, U.d_in, U.d_in + N, U.d_in + 3 * N, U.d_in + 6 * N, U.d_in + 2 * N, U.d_valid,
-              P->K[0], P->K[1], P->K[2], P->K[3], P->large_number, P->depth_magnitude_multiplier, P->normals_magnitude_multiplier};
-  hipLaunchKernelGGL(k_int_prepare, dim3(U.G), dim3(kIT), 0, st, pa, U.D);
+static int int_set_active(IntBatch& U, hipStream_t st) {
+  INT_TRY(hipMemcpyAsync(U.d_act, U.act.data(), sizeof(int32_t) * U.B, hipMemcpyHostToDevice, st));
+  INT_TRY(hipStreamSynchronize(st));  // U.act may change right after
+  return 0;
 }
 
-// preconditioned CG with scipy.sparse.linalg.cg semantics (x0 = D.z, M = 1/clip(diag), rtol); the
-// host looks at the done flag every 16 iterations
-static int int_run_cg(IntDev& D, int G, hipStream_t st, double rtol, int max_iter, int* its, bool* converged) {
-  INT_TRY(hipMemsetAsync(D.state, 0, sizeof(double) * 7, st));
-  hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(kIT), 0, st, D);
+static void int_launch_prepare(const mpsfm_int_problem* P0, IntBatch& U, hipStream_t st) {
+  const size_t BN = (size_t)U.B * U.N;
+  PrepArgs pa{P0->H, P0->W, U.d_in, U.d_in + BN, U.d_in + 3 * BN, U.d_in + 6 * BN, U.d_in + 2 * BN, U.d_valid, U.d_K,
+              P0->large_number, P0->depth_magnitude_multiplier, P0->normals_magnitude_multiplier};
+  hipLaunchKernelGGL(k_int_prepare, dim3(U.G, U.B), dim3(kIT), 0, st, pa, U.D);
+}
+
+// preconditioned CG with scipy.sparse.linalg.cg semantics (x0 = D.z, M = 1/clip(diag), rtol) on every
+// active image; an image stops updating when its own test is met.  The host looks at the done flags every
+// 16 iterations.  its[b] / conv[b] are written for the active images.
+static int int_run_cg(IntBatch& U, hipStream_t st, double rtol, int max_iter, int* its, bool* conv) {
+  IntDev& D = U.D;
+  const dim3 grid(U.G, U.B);
+  INT_TRY(hipMemsetAsync(D.state, 0, sizeof(double) * 8 * U.B, st));
+  hipLaunchKernelGGL(k_cg_init, grid, dim3(kIT), 0, st, D);
   int k = 0;
   bool done = false;
-  *its = 0;
   while (!done && k < max_iter) {
     const int batch = std::min(16, max_iter - k);
     for (int j = 0; j < batch; ++j, ++k) {
-      hipLaunchKernelGGL(k_cg_dir, dim3(G), dim3(kIT), 0, st, D, G, k, k == 0 ? 1 : 0, rtol);
-      hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(kIT), 0, st, D, G, k);
+      hipLaunchKernelGGL(k_cg_dir, grid, dim3(kIT), 0, st, D, U.G, k, k == 0 ? 1 : 0, rtol);
+      hipLaunchKernelGGL(k_cg_update, grid, dim3(kIT), 0, st, D, U.G, k);
     }
-    double hs[8];
-    INT_TRY(hipMemcpyAsync(hs, D.state, sizeof(hs), hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
-    done = hs[2] != 0.0;
-    *its = (int)hs[3];
+    INT_TRY(hipMemcpyAsync(U.hstate.data(), D.state, sizeof(double) * 8 * U.B, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
+    done = true;
+    for (int b = 0; b < U.B; ++b)
+      if (U.act[(size_t)b]) {
+        const bool db = U.hstate[(size_t)b * 8 + 2] != 0.0;
+        done = done && db;
+        its[b] = (int)U.hstate[(size_t)b * 8 + 3];
+        if (conv) conv[b] = db;
+      }
   }
   INT_TRY(hipGetLastError());
-  if (converged) *converged = done;
   return 0;
 }
 
@@ -432,101 +526,147 @@ static int int_run_cg(IntDev& D, int G, hipStream_t st, double rtol, int max_ite
 
 using namespace mpsfm;
 
-extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device, double* depth_out, mpsfm_int_summary* S) {
-  if (!P || !depth_out || !S) return ifail(MPSFM_EINVAL, "NULL argument");
+extern "C" int mpsfm_integrate_depth_batch(int32_t n_images, const mpsfm_int_problem* Ps, int32_t device, double* const* depth_out,
+                                           mpsfm_int_summary* Ss) {
+  if (n_images < 0) return ifail(MPSFM_EINVAL, "negative batch size");
+  if (n_images == 0) return 0;
+  if (!Ps || !depth_out || !Ss) return ifail(MPSFM_EINVAL, "NULL argument");
+  const int B = n_images;
+  const mpsfm_int_problem* P = &Ps[0];  // the shared configuration
   if (P->max_iter < 0 || P->max_iter > MPSFM_INT_MAX_IRLS) return ifail(MPSFM_EINVAL, "max_iter out of range");
-  if (int rc = int_check(P, device)) return rc;
+  for (int b = 0; b < B; ++b) {
+    if (!depth_out[b]) return ifail(MPSFM_EINVAL, "depth_out entry is NULL");
+    if (int rc = int_check(&Ps[b], device)) return rc;
+    if (!int_same_config(Ps[0], Ps[b])) return ifail(MPSFM_EINVAL, "images of a batch must share the map size and the configuration");
+  }
   INT_TRY(hipSetDevice(device));
-  std::memset(S, 0, sizeof(*S));
-  // a stream of its own: concurrent calls from different host threads (one image each) overlap on the GPU
+  std::memset(Ss, 0, sizeof(*Ss) * (size_t)B);
+  // a stream of its own: concurrent calls from different host threads overlap on the GPU
   StreamGuard sg;
   INT_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
   hipStream_t st = sg.st;
-  const int N = P->H * P->W;
-  IntSetup U;
-  if (int rc = int_setup(P, true, P->scale_filter != 0, st, U)) return rc;
+  const size_t N = (size_t)P->H * P->W;
+  IntBatch U;
+  if (int rc = int_setup(Ps, B, true, P->scale_filter != 0, st, U)) return rc;
   IntDev& D = U.D;
-  const int G = U.G;
-  const auto& ids = U.ids;
-  int32_t* d_ids = U.d_ids;
-  double* d_sp = U.d_sp;
-  double* d_out = U.d_out;
-  const bool keep_w = P->init && P->integrated && P->wu && P->wv;
-  if (keep_w) {
-    INT_TRY(hipMemcpyAsync(D.wu, P->wu, sizeof(double) * N, hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(D.wv, P->wv, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  const dim3 grid(U.G, B);
+  std::vector<int32_t> keep((size_t)B, 0);
+  for (int b = 0; b < B; ++b) {
+    keep[(size_t)b] = (Ps[b].init && Ps[b].integrated && Ps[b].wu && Ps[b].wv) ? 1 : 0;
+    if (keep[(size_t)b]) {
+      INT_TRY(hipMemcpyAsync(D.wu + (size_t)b * N, Ps[b].wu, sizeof(double) * N, hipMemcpyHostToDevice, st));
+      INT_TRY(hipMemcpyAsync(D.wv + (size_t)b * N, Ps[b].wv, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    }
   }
+  INT_TRY(hipMemcpyAsync(U.d_keep, keep.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
+  INT_TRY(hipStreamSynchronize(st));
   hipEvent_t e0, e1;
   INT_TRY(hipEventCreate(&e0)); INT_TRY(hipEventCreate(&e1));
   INT_TRY(hipEventRecord(e0, st));
   int_launch_prepare(P, U, st);
 
-  std::vector<double> hpart((size_t)G * 8);
-  auto energy = [&](int keep, double* out) -> int {
-    hipLaunchKernelGGL(k_int_weights, dim3(G), dim3(kIT), 0, st, D, P->k, P->lambda1, keep);
-    hipLaunchKernelGGL(k_int_sparse_energy, dim3(1), dim3(kIT), 0, st, (int)ids.size(), d_ids, d_sp, d_sp + ids.size(), D.z, P->lambda2,
-                       D.state + 7);
-    INT_TRY(hipMemcpyAsync(hpart.data(), D.part, sizeof(double) * hpart.size(), hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
-    double e_sparse;
-    INT_TRY(hipMemcpyAsync(&e_sparse, D.state + 7, sizeof(double), hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
-    double e_n = 0.0, e_d = 0.0;
-    for (int i = 0; i < G; ++i) { e_n += hpart[(size_t)i * 8]; e_d += hpart[(size_t)i * 8 + 1]; }
-    *out = e_n + e_d + (ids.empty() ? 0.0 : e_sparse);
+  // energies of the active images -> en[b]
+  std::vector<double> en((size_t)B, 0.0);
+  auto energy = [&]() -> int {
+    hipLaunchKernelGGL(k_int_weights, grid, dim3(kIT), 0, st, D, P->k, P->lambda1, (const int32_t*)U.d_keep);
+    hipLaunchKernelGGL(k_int_sparse_energy, dim3(B), dim3(kIT), 0, st, D, (const int32_t*)U.d_off, (const int32_t*)U.d_ids, (const double*)U.d_sp,
+                       (const double*)(U.d_sp + U.ids.size()), P->lambda2, U.d_esp);
+    INT_TRY(hipMemcpyAsync(U.hpart.data(), D.part, sizeof(double) * U.hpart.size(), hipMemcpyDeviceToHost, st));
+    INT_TRY(hipMemcpyAsync(U.hesp.data(), U.d_esp, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    INT_TRY(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) {
+      if (!U.act[(size_t)b]) continue;
+      double e_n = 0.0, e_d = 0.0;
+      const double* hp = U.hpart.data() + (size_t)b * U.G * 8;
+      for (int i = 0; i < U.G; ++i) { e_n += hp[(size_t)i * 8]; e_d += hp[(size_t)i * 8 + 1]; }
+      const bool has_sparse = U.sp_off[(size_t)b + 1] > U.sp_off[(size_t)b];
+      en[(size_t)b] = e_n + e_d + (has_sparse ? U.hesp[(size_t)b] : 0.0);
+    }
     return 0;
   };
   auto finish = [&](int rc) {
     float ms = 0.f;
     (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
-    S->ms = ms;
+    for (int b = 0; b < B; ++b) Ss[b].ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
   };
   auto save_weights = [&]() -> int {
-    if (P->wu) INT_TRY(hipMemcpyAsync(P->wu, D.wu, sizeof(double) * N, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
-    if (P->wv) INT_TRY(hipMemcpyAsync(P->wv, D.wv, sizeof(double) * N, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) {
+      if (Ps[b].wu) INT_TRY(hipMemcpyAsync(Ps[b].wu, D.wu + (size_t)b * N, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+      if (Ps[b].wv) INT_TRY(hipMemcpyAsync(Ps[b].wv, D.wv + (size_t)b * N, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    }
+    INT_TRY(hipStreamSynchronize(st));
     return 0;
   };
 
-  double en = 0.0;
-  if (int rc = energy(keep_w ? 1 : 0, &en)) return finish(rc);
-  S->energy_initial = S->energy_final = en;
-  S->energies[0] = en;
-  S->energy_old_out = P->energy_old;
-  S->integrated_out = P->integrated;
-  if (P->integrated && !(std::fabs(en - P->energy_old) / P->energy_old > P->tol)) {
-    if (int rc = save_weights()) return finish(rc);
-    return finish(0);  // energy has not changed: skip this frame (:433-437)
+  if (int rc = energy()) return finish(rc);
+  // after the first evaluation the weights are always recomputed (update_W after every CG solve)
+  std::fill(keep.begin(), keep.end(), 0);
+  INT_TRY(hipMemcpyAsync(U.d_keep, keep.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
+  std::vector<double> energy_0((size_t)B), min_energy((size_t)B);
+  std::vector<uint8_t> success((size_t)B, 1), ran((size_t)B, 0);
+  for (int b = 0; b < B; ++b) {
+    mpsfm_int_summary& S = Ss[b];
+    S.energy_initial = S.energy_final = en[(size_t)b];
+    S.energies[0] = en[(size_t)b];
+    S.energy_old_out = Ps[b].energy_old;
+    S.integrated_out = Ps[b].integrated;
+    energy_0[(size_t)b] = min_energy[(size_t)b] = en[(size_t)b];
+    // energy has not changed: skip this frame (:433-437)
+    if (Ps[b].integrated && !(std::fabs(en[(size_t)b] - Ps[b].energy_old) / Ps[b].energy_old > Ps[b].tol)) U.act[(size_t)b] = 0;
+    else ran[(size_t)b] = 1;
   }
-  const double energy_0 = en;
-  double min_energy = en;
-  bool success = true;
+  std::vector<int> cg_its((size_t)B, 0);
   for (int it = 0; it < P->max_iter; ++it) {
-    hipLaunchKernelGGL(k_int_system, dim3(G), dim3(kIT), 0, st, D, P->lambda1);
-    int cg_its = 0;
-    if (int rc = int_run_cg(D, G, st, P->cg_tol, P->cg_max_iter, &cg_its, nullptr)) return finish(rc);
-    S->cg_iters[it] = cg_its;
-    S->cg_iterations_total += cg_its;
-    const double energy_old = en;
-    min_energy = std::min(en, min_energy);
-    if (int rc = energy(0, &en)) return finish(rc);
-    S->irls_iterations = it + 1;
-    S->energies[it + 1] = en;
-    const double rel = std::fabs(en - energy_old) / energy_old, rel_min = std::fabs(en - min_energy) / min_energy;
-    if (((rel < P->tol && (energy_old - en) > 0) || (rel_min < P->tol && (min_energy - en) > 0)) && en < energy_0) break;
-    if (en > energy_0) { success = false; break; }
+    bool any = false;
+    for (int b = 0; b < B; ++b) any = any || U.act[(size_t)b];
+    if (!any) break;
+    if (int rc = int_set_active(U, st)) return finish(rc);
+    hipLaunchKernelGGL(k_int_system, grid, dim3(kIT), 0, st, D, P->lambda1);
+    if (int rc = int_run_cg(U, st, P->cg_tol, P->cg_max_iter, cg_its.data(), nullptr)) return finish(rc);
+    std::vector<double> energy_old(en);
+    for (int b = 0; b < B; ++b) if (U.act[(size_t)b]) min_energy[(size_t)b] = std::min(en[(size_t)b], min_energy[(size_t)b]);
+    if (int rc = energy()) return finish(rc);
+    for (int b = 0; b < B; ++b) {
+      if (!U.act[(size_t)b]) continue;
+      mpsfm_int_summary& S = Ss[b];
+      S.cg_iters[it] = cg_its[(size_t)b];
+      S.cg_iterations_total += cg_its[(size_t)b];
+      S.irls_iterations = it + 1;
+      S.energies[it + 1] = en[(size_t)b];
+      const double e = en[(size_t)b], eo = energy_old[(size_t)b], em = min_energy[(size_t)b];
+      const double rel = std::fabs(e - eo) / eo, rel_min = std::fabs(e - em) / em;
+      if (((rel < P->tol && (eo - e) > 0) || (rel_min < P->tol && (em - e) > 0)) && e < energy_0[(size_t)b]) U.act[(size_t)b] = 0;
+      else if (e > energy_0[(size_t)b]) { success[(size_t)b] = 0; U.act[(size_t)b] = 0; }
+    }
   }
-  S->energy_final = en;
-  S->integrated_out = 1;
   if (int rc = save_weights()) return finish(rc);
-  if (!success) {  // energy increased: keep the old map (:504-508)
-    S->energy_old_out = energy_0;
-    return finish(0);
+  bool any_changed = false;
+  for (int b = 0; b < B; ++b) {
+    mpsfm_int_summary& S = Ss[b];
+    if (!ran[(size_t)b]) continue;  // skipped frame: summary already says so
+    S.energy_final = en[(size_t)b];
+    S.integrated_out = 1;
+    if (!success[(size_t)b]) { S.energy_old_out = energy_0[(size_t)b]; continue; }  // energy increased: keep the old map (:504-508)
+    S.energy_old_out = en[(size_t)b];
+    S.changed = 1;
+    any_changed = true;
   }
-  S->energy_old_out = en;
-  S->changed = 1;
-  hipLaunchKernelGGL(k_int_exp, dim3(G), dim3(kIT), 0, st, N, D.z, d_out);
-  INT_TRY(hipMemcpyAsync(depth_out, d_out, sizeof(double) * N, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
+  if (any_changed) {
+    const size_t BN = (size_t)B * N;
+    hipLaunchKernelGGL(k_int_exp, dim3((unsigned)((BN + kIT - 1) / kIT)), dim3(kIT), 0, st, BN, (const double*)D.z, U.d_out);
+    for (int b = 0; b < B; ++b)
+      if (Ss[b].changed) INT_TRY(hipMemcpyAsync(depth_out[b], U.d_out + (size_t)b * N, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    INT_TRY(hipStreamSynchronize(st));
+  }
   return finish(0);
+}
+
+extern "C" int mpsfm_integrate_depth(const mpsfm_int_problem* P, int32_t device, double* depth_out, mpsfm_int_summary* S) {
+  if (!P || !depth_out || !S) return ifail(MPSFM_EINVAL, "NULL argument");
+  double* outs[1] = {depth_out};
+  return mpsfm_integrate_depth_batch(1, P, device, outs, S);
 }
 
 // IntegrationUncertainty.solve (reference integration.py:51-79) on the matrix of calculate_hessian
@@ -547,19 +687,23 @@ extern "C" int mpsfm_integration_variances(const mpsfm_int_problem* P, int32_t d
   INT_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
   hipStream_t st = sg.st;
   const int N = P->H * P->W;
-  IntSetup U;
-  if (int rc = int_setup(P, use_sparse != 0, false, st, U)) return rc;  // calculate_hessian applies no scale filter (:542)
+  IntBatch U;
+  if (int rc = int_setup(P, 1, use_sparse != 0, false, st, U)) return rc;  // calculate_hessian applies no scale filter (:542)
   IntDev& D = U.D;
+  const dim3 grid(U.G, 1);
+  int32_t zero = 0;
+  INT_TRY(hipMemcpyAsync(U.d_keep, &zero, sizeof(int32_t), hipMemcpyHostToDevice, st));
+  INT_TRY(hipStreamSynchronize(st));
   hipEvent_t e0, e1;
   INT_TRY(hipEventCreate(&e0)); INT_TRY(hipEventCreate(&e1));
   INT_TRY(hipEventRecord(e0, st));
   int_launch_prepare(P, U, st);
-  hipLaunchKernelGGL(k_int_weights, dim3(U.G), dim3(kIT), 0, st, D, P->k, P->lambda1, 0);  // init=False: weights from the checkpoint
-  hipLaunchKernelGGL(k_int_system, dim3(U.G), dim3(kIT), 0, st, D, P->lambda1);
-  hipLaunchKernelGGL(k_int_unit_rhs, dim3(U.G), dim3(kIT), 0, st, D);
+  hipLaunchKernelGGL(k_int_weights, grid, dim3(kIT), 0, st, D, P->k, P->lambda1, (const int32_t*)U.d_keep);  // init=False: weights from the checkpoint
+  hipLaunchKernelGGL(k_int_system, grid, dim3(kIT), 0, st, D, P->lambda1);
+  hipLaunchKernelGGL(k_int_unit_rhs, grid, dim3(kIT), 0, st, D);
   int its = 0;
   bool conv = false;
-  int rc = int_run_cg(D, U.G, st, rtol, max_iter, &its, &conv);
+  int rc = int_run_cg(U, st, rtol, max_iter, &its, &conv);
   float ms = 0.f;
   (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

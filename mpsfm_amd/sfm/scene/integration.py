@@ -184,15 +184,45 @@ def resize_linear(img, dsize):
 
 
 
-def integrate_bundle(images, workers: int = 8, cache_device="cpu"):
-    """Integrate several images concurrently (what MpsfmMapper.integrate_bundle loops over, reference
-    mpsfm/sfm/mapper/base.py:619-631).  Every call of mpsfm_integrate_depth runs on a HIP stream of its
-    own and ctypes releases the GIL, so the per-image launch sequences overlap on the GPU; results are
-    identical to integrating one image after the other.  Returns the per-image `changed` flags."""
+def integrate_bundle(images, workers: int = 8, cache_device="cpu", batched: bool = True):
+    """Integrate several images (what MpsfmMapper.integrate_bundle loops over, reference
+    mpsfm/sfm/mapper/base.py:619-631).  Images whose maps have the same size and configuration go through ONE
+    mpsfm_integrate_depth_batch call: every image keeps its own IRLS / CG state on the device, so the results
+    equal integrating one image after the other while launch and synchronisation latency is paid once.
+    `batched=False` falls back to concurrent single-image calls on `workers` host threads (each on a HIP
+    stream of its own).  Returns the per-image `changed` flags."""
     from concurrent.futures import ThreadPoolExecutor
 
+    from ... import capi
+
     images = list(images)
-    if workers <= 1 or len(images) <= 1:
-        return [im.integrate(cache_device=cache_device) for im in images]
-    with ThreadPoolExecutor(max_workers=min(workers, len(images))) as ex:
-        return list(ex.map(lambda im: im.integrate(cache_device=cache_device), images))
+    if not batched:
+        if workers <= 1 or len(images) <= 1:
+            return [im.integrate(cache_device=cache_device) for im in images]
+        with ThreadPoolExecutor(max_workers=min(workers, len(images))) as ex:
+            return list(ex.map(lambda im: im.integrate(cache_device=cache_device), images))
+    groups: dict = {}
+    for idx, im in enumerate(images):
+        assert im.image.has_pose and im.depth.activated, "Image not registered or depth map not activated"
+        kwargs, _ = im._prepare_integration_variables()
+        nunc = np.asarray(im.normals.uncertainty)
+        nvar = np.stack([nunc[..., 0, 0], nunc[..., 1, 1], nunc[..., 2, 2]], -1) if nunc.ndim == 4 else nunc
+        item = dict(depth_prior=im.depth.data_prior, depth_uncertainty=im.depth.uncertainty, valid=im.depth.valid, normals=im.normals.data,
+                    normals_var=nvar, depth_init=im.depth.data, K=kwargs["K"], kps=kwargs["kps"], depth3d=kwargs["depth3d"],
+                    zvars3d=kwargs["zvars3d"], init=True, integrated=im.integrated, energy_old=im.energy_old or 0.0, wu=im.wu, wv=im.wv)
+        conf = im._solver_conf()
+        key = (np.asarray(im.depth.data).shape, tuple(sorted(conf.items())))
+        groups.setdefault(key, []).append((idx, im, item, conf))
+    changed = [False] * len(images)
+    for members in groups.values():
+        res = capi.integrate_depth_batch([m[2] for m in members], conf=members[0][3])
+        for (idx, im, _, _), (depth, summary, wu, wv) in zip(members, res):
+            im.last_integration_summary = summary
+            im.integrated, im.energy_old, im.wu, im.wv = summary["integrated"], summary["energy_old"], wu, wv
+            if depth is None:
+                im.count_integrated += 1
+                continue
+            im.count_skipped += 1
+            im.depth.data = depth
+            changed[idx] = True
+    return changed

@@ -20,3 +20,9 @@ print(f"oracle (scipy cg): {1e3*(t1-t0):.1f} ms, cg {info['cg_iters']}; max rel 
 # algorithmic bytes of one CG iteration: 5-point stencil on N doubles: read d,cr,cd (3), zz,p (2+halo), write p,q (2); update: read p,q,r,z,minv (5) write z,r,zz (3)
 N = 290 * 387
 print("bytes per CG iteration (algorithmic):", 15 * 8 * N, "-> GB/s at measured rate:", 15 * 8 * N * sum(s['cg_iters']) / (s['ms'] * 1e-3) / 1e9)
+
+if len(sys.argv) > 1 and sys.argv[1] == "variances":  # row f4: one solve H y = 1 serves every query pixel
+    q = np.stack([np.arange(387), np.arange(387) % 290], 1)
+    for i in range(2):
+        t0 = time.perf_counter(); v, sv = capi.integration_variances(*args[:7], q); t1 = time.perf_counter()
+        print(f"variances: wall {1e3*(t1-t0):.1f} ms, device {sv['ms']:.2f} ms, cg {sv['cg_iterations']}, converged {sv['converged']}", flush=True)

@@ -10,4 +10,6 @@ CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $CMD > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- $CMD > "$OUT/bench_write.json" 2> "$OUT/write.err"
+# row f1 / f4 kernels (depth integration, variances) in their own trace
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_int" -- python3 scripts/bench_integration.py variances > "$OUT/bench_integration.log" 2> "$OUT/trace_int.err"
 python3 scripts/summarize_profile.py "$OUT" "$TAG"

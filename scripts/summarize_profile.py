@@ -19,6 +19,18 @@ if stats:
         for r in rows:
             w.writerow([r["Name"][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
+stats_int = find("trace_int", "*kernel_stats.csv")
+if stats_int:
+    rows = list(csv.DictReader(open(stats_int)))
+    with open(os.path.join(dst, f"{tag}_integration_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r["Name"][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    log = os.path.join(out, "bench_integration.log")
+    if os.path.exists(log):
+        open(os.path.join(dst, f"{tag}_integration_bench.log"), "w").write(open(log).read())
+
 summary = {}
 for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     f = find(d, "*counter_collection.csv")

@@ -281,3 +281,95 @@ def test_int_covs_at_kps_through_the_mixin():
     # the whole-image variant (ignore_depths=False in the reference's signature) reuses the cached Hessian
     full = img.calculate_int_covs_for_entire_image(downscaled=True)
     assert full.shape == (H, W) and np.all(full > 0)
+
+
+# ---- batched integration (integrate_bundle) --------------------------------------------------------------
+
+def _item(maps, **extra):
+    nu = maps["normals_uncertainty"]
+    d = dict(depth_prior=maps["depth_prior"], depth_uncertainty=maps["depth_uncertainty"], valid=maps["valid"], normals=maps["normals"],
+             normals_var=np.stack([nu[..., 0, 0], nu[..., 1, 1], nu[..., 2, 2]], -1), depth_init=maps["depth_init"], K=maps["K"],
+             kps=maps["kps"], depth3d=maps["depth3d"], zvars3d=maps["zvars3d"])
+    d.update(extra)
+    return d
+
+
+@pytest.mark.gpu
+def test_batched_integration_equals_single_calls():
+    """mpsfm_integrate_depth_batch: images with different content, different numbers of sparse points (one
+    with none), one already integrated frame that is skipped and one whose IRLS needs more steps — every
+    image must come out exactly as from its own mpsfm_integrate_depth call."""
+    import time
+
+    cases = [make_maps(145, 193, seed=200 + i, n_sparse=[400, 0, 50, 900, 400, 10][i % 6], prior_noise=[0.05, 0.02, 0.1][i % 3])
+             for i in range(12)]
+    singles = [_hip(m) for m in cases]
+    # image 3 is fed back in its integrated state: must be skipped (changed False) in both paths
+    d3, s3, wu3, wv3 = singles[3]
+    again = dict(cases[3], depth_init=d3)
+    extra3 = dict(init=True, integrated=True, energy_old=s3["energy_old"], wu=wu3, wv=wv3)
+    single_again = _hip(again, **extra3)
+    items = [_item(m) for m in cases] + [_item(again, **extra3)]
+    _ = capi.integrate_depth_batch(items[:2])  # warm up
+    t0 = time.perf_counter()
+    batch = capi.integrate_depth_batch(items)
+    t_batch = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _ = [_hip(m) for m in cases]
+    t_seq = time.perf_counter() - t0
+    assert len(batch) == 13
+    for (d1, s1, wu1, wv1), (d2, s2, wu2, wv2) in zip(singles + [single_again], batch):
+        assert s1["changed"] == s2["changed"] and s1["cg_iters"] == s2["cg_iters"] and s1["irls_iterations"] == s2["irls_iterations"]
+        assert s1["energies"] == s2["energies"] and s1["energy_old"] == s2["energy_old"] and s1["integrated"] == s2["integrated"]
+        if d1 is None:
+            assert d2 is None
+        else:
+            np.testing.assert_array_equal(d1, d2)
+        np.testing.assert_array_equal(wu1, wu2)
+        np.testing.assert_array_equal(wv1, wv2)
+    assert batch[12][0] is None and not batch[12][1]["changed"]
+    assert len({tuple(s["cg_iters"]) for _, s, _, _ in batch}) > 3  # the images really differ
+    print(f"12 images 145x193: one by one {1e3 * t_seq:.1f} ms, one batch {1e3 * t_batch:.1f} ms (device {batch[0][1]['ms']:.1f} ms)")
+    assert t_batch < t_seq
+    # mixed sizes or configurations in one batch are refused
+    with pytest.raises(capi.MpsfmHipError):
+        capi.integrate_depth_batch([_item(cases[0]), _item(make_maps(40, 52, seed=1))])
+    assert capi.integrate_depth_batch([]) == []
+
+
+@pytest.mark.gpu
+def test_integrate_bundle_batched_on_a_scene():
+    """integrate_bundle(images): the mixin gathers every image like Image.integrate() and runs ONE batch; equal to
+    integrating the images one after the other."""
+    from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
+    from mpsfm_amd.sfm.scene.integration import integrate_bundle
+    from mpsfm_amd.sfm.scene.numpy_integrable import NumpyIntegrableImage, NumpyNormals
+    from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+    from mpsfm_amd.synthetic import make_scene
+
+    def build():
+        prob, truth = make_scene(6, 400, True, seed=53)
+        sc = scene_from_problem(prob, truth, map_size=(64, 48), seed=4)
+        Optimizer({}, sc, None).calculate_point_covs({"optim_ids": set(sc.images), "pts3D": set(sc.points3D), "constpoints": set()})
+        rng = np.random.default_rng(2)
+        imgs = []
+        for imid in sorted(sc.images):
+            H, W = sc.images[imid].depth.data.shape
+            n = rng.normal(0, 0.05, (H, W, 3)) + np.array([0.0, 0.0, -1.0])
+            n /= np.linalg.norm(n, axis=-1, keepdims=True)
+            c = np.zeros((H, W, 3, 3))
+            c[..., 0, 0] = c[..., 1, 1] = c[..., 2, 2] = 0.05**2
+            imgs.append(NumpyIntegrableImage(sc, imid, NumpyNormals(n, c)))
+        return imgs
+
+    a, b = build(), build()
+    ch_a = [im.integrate() for im in a]
+    ch_b = integrate_bundle(b)
+    assert ch_a == ch_b and any(ch_a)
+    for x, y in zip(a, b):
+        # the two scenes got their point covariances from two GPU runs (atomics: last-bit differences)
+        np.testing.assert_allclose(x.depth.data, y.depth.data, rtol=1e-11)
+        assert x.energy_old == pytest.approx(y.energy_old, rel=1e-11) and x.integrated == y.integrated
+        assert x.last_integration_summary["cg_iters"] == y.last_integration_summary["cg_iters"]
+    assert integrate_bundle(b) == [False] * len(b)  # nothing changed since: every frame is skipped
+    assert integrate_bundle(b, batched=False) == [False] * len(b)
