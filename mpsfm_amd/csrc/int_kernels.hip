@@ -23,6 +23,10 @@ static int ifail(int code, const std::string& m) { g_err = m; return code; }
   } while (0)
 
 constexpr int kIT = 256;  // threads per workgroup
+#ifndef MPSFM_INT_PIX
+#define MPSFM_INT_PIX 1
+#endif
+constexpr int kPix = MPSFM_INT_PIX;  // pixels per thread in the CG kernels (1, 2, 4, 8 measured equal: the kernels are latency-bound)
 
 // A batch of B images of one size: every per-pixel array is [B][N] (w4: [B][4][N]); part is [B][G][8],
 // state [B][8].  Kernels are launched on a (G, B) grid; blockIdx.y picks the image.
@@ -239,14 +243,17 @@ __device__ __forceinline__ double stencil_apply(const IntDev& D, const double* x
 __global__ __launch_bounds__(kIT) void k_cg_init(IntDev Dall) {
   if (!Dall.act[blockIdx.y]) return;
   const IntDev D = int_image(Dall, blockIdx.y);
-  const int p = blockIdx.x * kIT + threadIdx.x;
   double v[3] = {0.0, 0.0, 0.0};
-  if (p < D.N) {
-    const int row = p / D.W, col = p - row * D.W;
-    const double r = D.b[p] - stencil_apply(D, D.z, p, row, col);
-    const double zz = D.minv[p] * r;
-    D.r[p] = r; D.zz[p] = zz;
-    v[0] = r * zz; v[1] = r * r; v[2] = D.b[p] * D.b[p];
+#pragma unroll
+  for (int u = 0; u < kPix; ++u) {
+    const int p = (blockIdx.x * kPix + u) * kIT + threadIdx.x;
+    if (p < D.N) {
+      const int row = p / D.W, col = p - row * D.W;
+      const double r = D.b[p] - stencil_apply(D, D.z, p, row, col);
+      const double zz = D.minv[p] * r;
+      D.r[p] = r; D.zz[p] = zz;
+      v[0] += r * zz; v[1] += r * r; v[2] += D.b[p] * D.b[p];
+    }
   }
   block_partials<3>(v, D.part);
 }
@@ -268,20 +275,23 @@ __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it
   }
   const double* pold = (it & 1) ? D.p1 : D.p0;
   double* pnew = (it & 1) ? D.p0 : D.p1;
-  const int p = blockIdx.x * kIT + threadIdx.x;
   double v[1] = {0.0};
-  if (!done && p < D.N) {
-    const int W = D.W, H = D.H;
-    const int row = p / W, col = p - row * W;
-    auto pn = [&](int q) { return first ? D.zz[q] : D.zz[q] + beta * pold[q]; };
-    const double pc = pn(p);
-    double q = D.d[p] * pc;
-    if (col >= 1) q += D.cr[p - 1] * pn(p - 1);
-    if (col <= W - 2) q += D.cr[p] * pn(p + 1);
-    if (row >= 1) q += D.cd[p - W] * pn(p - W);
-    if (row <= H - 2) q += D.cd[p] * pn(p + W);
-    pnew[p] = pc; D.q[p] = q;
-    v[0] = pc * q;
+#pragma unroll
+  for (int u = 0; u < kPix; ++u) {
+    const int p = (blockIdx.x * kPix + u) * kIT + threadIdx.x;
+    if (!done && p < D.N) {
+      const int W = D.W, H = D.H;
+      const int row = p / W, col = p - row * W;
+      auto pn = [&](int q) { return first ? D.zz[q] : D.zz[q] + beta * pold[q]; };
+      const double pc = pn(p);
+      double q = D.d[p] * pc;
+      if (col >= 1) q += D.cr[p - 1] * pn(p - 1);
+      if (col <= W - 2) q += D.cr[p] * pn(p + 1);
+      if (row >= 1) q += D.cd[p - W] * pn(p - W);
+      if (row <= H - 2) q += D.cd[p] * pn(p + W);
+      pnew[p] = pc; D.q[p] = q;
+      v[0] += pc * q;
+    }
   }
   // the partial slots 0..2 are still being read by slower workgroups of this launch: use slots 4..
   __syncthreads();
@@ -308,17 +318,20 @@ __global__ __launch_bounds__(kIT) void k_cg_update(IntDev Dall, int nblocks, int
     if (!done) { D.state[0] = D.state[4]; D.state[3] += 1.0; }
   }
   const double* pnew = (it & 1) ? D.p0 : D.p1;
-  const int p = blockIdx.x * kIT + threadIdx.x;
   double v[2] = {0.0, 0.0};
-  if (p < D.N) {
-    double r = D.r[p];
-    if (!done) {
-      D.z[p] += alpha * pnew[p];
-      r -= alpha * D.q[p];
-      D.r[p] = r;
-      D.zz[p] = D.minv[p] * r;
+#pragma unroll
+  for (int u = 0; u < kPix; ++u) {
+    const int p = (blockIdx.x * kPix + u) * kIT + threadIdx.x;
+    if (p < D.N) {
+      double r = D.r[p];
+      if (!done) {
+        D.z[p] += alpha * pnew[p];
+        r -= alpha * D.q[p];
+        D.r[p] = r;
+        D.zz[p] = D.minv[p] * r;
+      }
+      v[0] += r * D.zz[p]; v[1] += r * r;
     }
-    v[0] = r * D.zz[p]; v[1] = r * r;
   }
   block_partials<2>(v, D.part);
 }
@@ -497,7 +510,8 @@ static void int_launch_prepare(const mpsfm_int_problem* P0, IntBatch& U, hipStre
 // 16 iterations.  its[b] / conv[b] are written for the active images.
 static int int_run_cg(IntBatch& U, hipStream_t st, double rtol, int max_iter, int* its, bool* conv) {
   IntDev& D = U.D;
-  const dim3 grid(U.G, U.B);
+  const int Gc = (int)((U.N + (size_t)kIT * kPix - 1) / ((size_t)kIT * kPix));  // workgroups (= partial rows) of the CG kernels
+  const dim3 grid(Gc, U.B);
   INT_TRY(hipMemsetAsync(D.state, 0, sizeof(double) * 8 * U.B, st));
   hipLaunchKernelGGL(k_cg_init, grid, dim3(kIT), 0, st, D);
   int k = 0;
@@ -505,8 +519,8 @@ static int int_run_cg(IntBatch& U, hipStream_t st, double rtol, int max_iter, in
   while (!done && k < max_iter) {
     const int batch = std::min(16, max_iter - k);
     for (int j = 0; j < batch; ++j, ++k) {
-      hipLaunchKernelGGL(k_cg_dir, grid, dim3(kIT), 0, st, D, U.G, k, k == 0 ? 1 : 0, rtol);
-      hipLaunchKernelGGL(k_cg_update, grid, dim3(kIT), 0, st, D, U.G, k);
+      hipLaunchKernelGGL(k_cg_dir, grid, dim3(kIT), 0, st, D, Gc, k, k == 0 ? 1 : 0, rtol);
+      hipLaunchKernelGGL(k_cg_update, grid, dim3(kIT), 0, st, D, Gc, k);
     }
     INT_TRY(hipMemcpyAsync(U.hstate.data(), D.state, sizeof(double) * 8 * U.B, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
     done = true;
