@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   if (MODE == MODE_FULL && ents_in_lds)
     for (int i = tid; i < H.nent; i += kThreads) s_ents[i] = A.ents[H.ent0 + i];
   __syncthreads();
+  if (A.dbg & 8) return;  // ablation: stop after P0
 
   // ---- P1: per-record residual / Jacobian, J^T J blocks ------------------------------------
   double my_cost = 0.0;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     }
   }
   __syncthreads();
+  if (A.dbg & 16) return;  // ablation: stop after P1
 
   // ---- P2: per-landmark (V + D)^-1 ------------------------------------------------------------
   double my_gmax = 0.0;
