@@ -268,17 +268,16 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
       V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
       V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
-      if (!spd3_inverse(V, Vi)) {
+      // Vi <- F = L^-1 of V + D = L L^T: the Schur products become Z Z'^T with Z = W F^T (see spd3_inv_factor)
+      if (!spd3_inv_factor(V, Vi)) {
         my_bad = 1;
 #pragma unroll
         for (int k = 0; k < 6; ++k) Vi[k] = 0.0;
       }
       const double g0 = s_g[tid * 3], g1 = s_g[tid * 3 + 1], g2 = s_g[tid * 3 + 2];
-      double vg[3];
-      sym3_mul(Vi, g0, g1, g2, vg);
 #pragma unroll
       for (int k = 0; k < 6; ++k) s_V[tid * 6 + k] = Vi[k];
-      s_g[tid * 3] = vg[0]; s_g[tid * 3 + 1] = vg[1]; s_g[tid * 3 + 2] = vg[2];
+      s_g[tid * 3] = Vi[0] * g0; s_g[tid * 3 + 1] = Vi[1] * g0 + Vi[2] * g1; s_g[tid * 3 + 2] = Vi[3] * g0 + Vi[4] * g1 + Vi[5] * g2;  // F g
       const double p0 = A.ps[3 * pix], p1 = A.ps[3 * pix + 1], p2 = A.ps[3 * pix + 2];
       my_gmax = fmax(fabs(g0 / p0), fmax(fabs(g1 / p1), fabs(g2 / p2)));
     }
@@ -291,19 +290,27 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       const int lcam = my_meta & 0xff;
       const int lpt = (my_meta >> 8) & 0xff;
       if (lcam != (int)kLcamConst && A.pt_kv[H.pt0 + lpt] != 0xffff) {
-        const double* w = &s_W[tid * kWStride];
+        double* w = &s_W[tid * kWStride];
         const double v0 = s_g[lpt * 3], v1 = s_g[lpt * 3 + 1], v2 = s_g[lpt * 3 + 2];
+        const double f00 = s_V[lpt * 6], f10 = s_V[lpt * 6 + 1], f11 = s_V[lpt * 6 + 2], f20 = s_V[lpt * 6 + 3], f21 = s_V[lpt * 6 + 4],
+                     f22 = s_V[lpt * 6 + 5];
         const int slot = s_slot[lcam];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          const double x = w[i * 3] * v0 + w[i * 3 + 1] * v1 + w[i * 3 + 2] * v2;
+          // W -> Z = W F^T in place (this thread owns the row block of its record)
+          const double w0 = w[i * 3], w1 = w[i * 3 + 1], w2 = w[i * 3 + 2];
+          const double z0 = w0 * f00, z1 = w0 * f10 + w1 * f11, z2 = w0 * f20 + w1 * f21 + w2 * f22;
+          w[i * 3] = z0; w[i * 3 + 1] = z1; w[i * 3 + 2] = z2;
+          const double x = z0 * v0 + z1 * v1 + z2 * v2;
           if (lcam < kTileCams) atomicAdd(&s_wv[lcam * 6 + i], x);
           else atomicAdd(&A.wv[(size_t)slot * 6 + i], x);
         }
       }
     }
 
-    // ---- P3b: Schur pairs, block-major:  S[ci,cj] -= sum_pairs (W_i Vinv) W_j^T ------------------
+    __syncthreads();  // the rows of s_W now hold Z
+
+    // ---- P3b: Schur pairs, block-major:  S[ci,cj] -= sum_pairs Z_i Z_j^T  (= W_i (V+D)^-1 W_j^T) ---------
     // Rounds of kGroups blocks: six lanes sum one block in registers, park it in LDS, then the whole
     // workgroup flushes the round with lanes running along the 36 contiguous doubles of a block
     // (the access shape global atomics want).
@@ -324,20 +331,16 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
             const uint32_t cur = ent;
             ++e;
             if (e < e1) ent = ep[e];  // fetch the next pair while this one is processed
-            const int ri = cur & 0xff, rj = (cur >> 8) & 0xff, lpt = (cur >> 16) & 0xff;
-            const double* wi = &s_W[ri * kWStride + row * 3];
-            // 16-byte LDS reads: (V+D)^-1 (3 x b128) and W_j (9 x b128) are shared by the six lanes of the group
-            double Vi[6], wj[18];
+            const int ri = cur & 0xff, rj = (cur >> 8) & 0xff;
+            const double* zi = &s_W[ri * kWStride + row * 3];
+            // 16-byte LDS reads: Z_j (9 x b128) is shared by the six lanes of the group
+            double wj[18];
             {
-              const double2* v2 = reinterpret_cast<const double2*>(&s_V[lpt * 6]);
-#pragma unroll
-              for (int k = 0; k < 3; ++k) { const double2 t = v2[k]; Vi[2 * k] = t.x; Vi[2 * k + 1] = t.y; }
               const double2* w2 = reinterpret_cast<const double2*>(&s_W[rj * kWStride]);
 #pragma unroll
               for (int k = 0; k < 9; ++k) { const double2 t = w2[k]; wj[2 * k] = t.x; wj[2 * k + 1] = t.y; }
             }
-            double y[3];
-            sym3_mul(Vi, wi[0], wi[1], wi[2], y);
+            const double y[3] = {zi[0], zi[1], zi[2]};
 #pragma unroll
             for (int bb = 0; bb < 6; ++bb) acc[bb] += y[0] * wj[bb * 3] + y[1] * wj[bb * 3 + 1] + y[2] * wj[bb * 3 + 2];
           }

@@ -147,6 +147,28 @@ __host__ __device__ inline bool spd3_inverse(const double* V, double* Vi) {
   return true;
 }
 
+// The inverse Cholesky factor of a 3x3 SPD matrix: V = L L^T, F = L^-1 (lower), packed [00 10 11 20 21 22],
+// so that V^-1 = F^T F.  With Z = W F^T:  W V^-1 W'^T = Z Z'^T  and  W V^-1 g = Z (F g).
+__host__ __device__ inline bool spd3_inv_factor(const double* V, double* F) {
+  const double a = V[0], b = V[1], c = V[2], d = V[3], e = V[4], f = V[5];
+  if (!(a > 0.0)) return false;
+  const double l00 = sqrt(a);
+  const double l10 = b / l00, l20 = c / l00;
+  const double t11 = d - l10 * l10;
+  if (!(t11 > 0.0)) return false;
+  const double l11 = sqrt(t11);
+  const double l21 = (e - l20 * l10) / l11;
+  const double t22 = f - l20 * l20 - l21 * l21;
+  if (!(t22 > 0.0)) return false;
+  const double l22 = sqrt(t22);
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  F[0] = i00; F[1] = i10; F[2] = i11; F[3] = i20; F[4] = i21; F[5] = i22;
+  return true;
+}
+
 __host__ __device__ inline void sym3_mul(const double* S, double v0, double v1, double v2, double* o) {
   o[0] = S[0] * v0 + S[1] * v1 + S[2] * v2;
   o[1] = S[1] * v0 + S[3] * v1 + S[4] * v2;
