@@ -21,6 +21,8 @@ CONFIGS = {
     "C2": (50, 20_000, False),
     "C3": (200, 150_000, True),
     "C4": (1000, 800_000, True),
+    # BASELINE config 5 in shape: 300 images, dense matches (~2 M reprojection observations), priors on
+    "C5": (300, 400_000, True),
 }
 
 FX = FY = 1200.0

@@ -378,3 +378,49 @@ def test_two_process_sharded_solve_on_one_gpu(tmp_path):
         st = np.load(tmp_path / f"state{r}.npz")
         np.testing.assert_allclose(st["cam_t"], ref.cam_t, atol=1e-7)
         np.testing.assert_allclose(st["pts"], ref.pts[o["lo"]:o["hi"]], atol=1e-6)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["C4", "C5"])
+def test_full_size_properties_large_configs(name):
+    """BASELINE configs 4 (1000 cameras / 800k landmarks) and 5 (300 cameras, ~2 M observations) on one GPU:
+    size-independent properties of the solve, then the retriangulation numerics over every track of the
+    refined scene with a sample checked against the oracle."""
+    prob, truth = make_config(name)
+    ref_q0, ref_t1 = prob.cam_quat[0].copy(), prob.cam_t[1, 0]
+    if name == "C5":
+        assert prob.n_obs > 1_800_000
+    with capi.BAHandle(prob) as h:
+        c0 = sum(h.eval_cost())
+        s = h.solve()
+        c1 = sum(h.eval_cost())
+        assert s["initial_cost"] == pytest.approx(c0, rel=1e-10) and s["final_cost"] == pytest.approx(c1, rel=1e-10)
+        tc = np.array(s["trace_cost"])
+        assert np.all(np.diff(tc) <= 1e-9 * tc[:-1]) and s["final_cost"] < 0.2 * s["initial_cost"]
+        assert s["termination"] in ("function_tolerance", "parameter_tolerance") and s["num_iterations"] <= 50
+        assert s["num_residual_blocks"] == prob.n_obs + prob.n_dobs and s["reduced_dim"] == 6 * (prob.n_cams - 1)
+        h.get_state()
+        np.testing.assert_array_equal(prob.cam_quat[0], ref_q0)
+        assert prob.cam_t[1, 0] == ref_t1
+        print(f"{name}: {s['num_iterations']} LM iterations, {1e3 * s['time_total_s']:.1f} ms, dense {1e3 * s['time_dense_s']:.1f} ms, "
+              f"sweep {1e3 * s['time_linearize_s']:.1f} ms")
+    # retriangulation numerics on all tracks with the refined poses
+    order = np.argsort(prob.obs_pt, kind="stable")
+    start = np.searchsorted(prob.obs_pt[order], np.arange(prob.n_pts + 1))
+    tr = Tracks(prob.cam_quat, prob.cam_t, prob.cam_intr, prob.cam_intr_idx, start, prob.obs_cam[order], prob.obs_xy[order])
+    x = capi.triangulate_tracks(tr)
+    ang, err, front = capi.filter_tracks(tr, x)
+    assert x.shape == (prob.n_pts, 3) and np.isfinite(x).mean() > 0.999 and front.mean() > 0.95
+    assert np.nanmedian(np.linalg.norm(x - prob.pts, axis=1)) < 0.1
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(prob.n_pts, 3000, replace=False))
+    cnt = np.diff(start)[pick]
+    s2 = np.concatenate([[0], np.cumsum(cnt)])
+    idx = np.concatenate([np.arange(start[p], start[p + 1]) for p in pick])
+    sub = Tracks(prob.cam_quat, prob.cam_t, prob.cam_intr, prob.cam_intr_idx, s2, tr.el_cam[idx], tr.el_xy[idx])
+    x_o = O.triangulate_tracks(sub)
+    np.testing.assert_allclose(x[pick], x_o, rtol=0, atol=1e-8)
+    a_o, e_o, f_o = O.filter_tracks(sub, x[pick])
+    np.testing.assert_allclose(ang[pick], a_o, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(err[idx], e_o, rtol=1e-9, atol=1e-11)  # reprojection errors are per track element
+    np.testing.assert_array_equal(front[idx], f_o)                      # so are the cheirality flags
