@@ -6,6 +6,8 @@
 // row-major inside a tile.  Tile row `nt` (one extra) carries the right-hand side in its row 0, so
 // the forward substitution z = L^-1 rhs falls out of the factorisation; k_backsub then solves
 // L^T y = z.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mpsfm {
@@ -302,6 +304,80 @@ __device__ __forceinline__ void half_syrk_sub(const double* __restrict__ At, con
     for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[ni][s], acc[ni], 0, 0, 0);
 }
 
+// ---- trailing update of an outer panel: 64x64 output block per workgroup ---------------------------
+// C(ti, tk) -= sum_{c = c0..j} L(ti, c) L(tk, c)^T for the tiles right of the panel.  One wave per 32x32 output
+// tile of a 2x2 tile block; the four operand tiles of a panel column (two row tiles, two column tiles) are
+// staged in LDS once per workgroup and double-buffered against the MFMAs, so every operand byte fetched from
+// L2 feeds 8 flops instead of 2.7 (the per-tile kernel is L2-bandwidth-bound at ~25 % of the MFMA peak).
+constexpr int kLdsLd = 34;  // LDS row stride of a staged tile (doubles): 16-byte aligned rows, banks spread
+template <int LD>
+__device__ __forceinline__ void tile_syrk_sub_lds(const double* At, const double* Bt, int lane, v4d acc[2][2]) {
+  const int row = lane & 15, kg = lane >> 4;
+  double a[2][8], b[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const double2* pa = reinterpret_cast<const double2*>(At + (16 * h + row) * LD + 8 * kg);
+    const double2* pb = reinterpret_cast<const double2*>(Bt + (16 * h + row) * LD + 8 * kg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double2 x = pa[s], y = pb[s];
+      a[h][2 * s] = -x.x; a[h][2 * s + 1] = -x.y;
+      b[h][2 * s] = y.x;  b[h][2 * s + 1] = y.y;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_big_update(double* A, int nt, int j, int c0) {
+  __shared__ __attribute__((aligned(16))) double s_t[2][4][kTile * kLdsLd];
+  const int bx = blockIdx.x, by = blockIdx.y;
+  if (bx < by) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tk0 = j + 1;
+  const int ti0 = tk0 + 2 * bx, tkb = tk0 + 2 * by;
+  const int ti = ti0 + (wave & 1), tk = tkb + (wave >> 1);
+  const bool valid = (ti <= nt) && (tk <= nt - 1) && (ti >= tk);
+  // staging: thread -> (tile t, 16-byte piece q); 4 tiles x 512 pieces, 8 pieces per thread
+  double2 pre[8];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + 256 * u, t = idx >> 9, q = idx & 511;
+      const int trow = (t < 2) ? ti0 + t : tkb + (t - 2);
+      const bool ok = (t < 2) ? (trow <= nt) : (trow <= nt - 1);
+      pre[u] = ok ? reinterpret_cast<const double2*>(A + lt_tile(trow, c) * kTileElems)[q] : make_double2(0.0, 0.0);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + 256 * u, t = idx >> 9, q = idx & 511;
+      const int r = q >> 4, c2 = q & 15;  // row, double2 column
+      *reinterpret_cast<double2*>(&s_t[buf][t][r * kLdsLd + 2 * c2]) = pre[u];
+    }
+  };
+  v4d acc[2][2];
+  double* C = A + lt_tile(valid ? ti : tk0, valid ? tk : tk0) * kTileElems;
+  if (valid) tile_load_acc(C, lane, acc);
+  fetch(c0);
+  park(0);
+  __syncthreads();
+  for (int c = c0; c <= j; ++c) {
+    const int buf = (c - c0) & 1;
+    if (c < j) fetch(c + 1);
+    if (valid) tile_syrk_sub_lds<kLdsLd>(s_t[buf][wave & 1], s_t[buf][2 + (wave >> 1)], lane, acc);
+    if (c < j) park(buf ^ 1);
+    __syncthreads();
+  }
+  if (valid) tile_store_acc(C, kTile, lane, acc);
+}
+
 int g_dbg_flags = 0;
 extern "C" void mpsfm_debug_set(int f) { g_dbg_flags = f; }
 
@@ -311,7 +387,14 @@ extern "C" void mpsfm_debug_set(int f) { g_dbg_flags = f; }
 //                              wave 1 updates the workgroup's own tile meanwhile and then solves it
 //                              against the factor (X L^-T); the workgroup that owns the diagonal tile
 //                              stores L and L^-T (kept for the back substitution).
-__global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg) {
+// Outer panels (large matrices): c0 is the first tile column whose L is applied to a trailing tile in this
+// launch (c0 == j: the plain right-looking step), tk_max the last tile column this launch touches, and
+//   kStepNoOwnUpdate  the panel column j+1 has already received column j (first step of an outer panel),
+//   kStepBig          no factorisation: every tile (ti, tk), j < tk <= tk_max, gets columns c0..j at once
+//                     (one load and one store of the tile for a rank-32*(j-c0+1) update).
+constexpr int kStepNoOwnUpdate = 1, kStepBig = 2;
+__global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg, int c0, int tk_max,
+                                                   int mode) {
   __shared__ double s_T[kTile][kTile + 1];
   __shared__ double s_X[kTile][kTile + 1];
   __shared__ double s_Lt[kTile * kTile];
@@ -321,15 +404,17 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tk = j + 1 + blockIdx.y;
   const int ti = j + 1 + blockIdx.x;
-  if (ti < tk || tk >= nt || ti > nt) return;
+  if (ti < tk || tk >= nt || ti > nt || tk > tk_max) return;
   double* C = A + lt_tile(ti, tk) * kTileElems;
-  if (tk != j + 1) {
+  if (tk != j + 1 || (mode & kStepBig)) {
     v4d acc[2];
     half_load_acc(C, lane, wave, acc);
-    if (!(dbg & 4)) half_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, wave, acc);
+    if (!(dbg & 4))
+      for (int c = c0; c <= j; ++c) half_syrk_sub(A + lt_tile(ti, c) * kTileElems, A + lt_tile(tk, c) * kTileElems, lane, wave, acc);
     half_store_acc(C, lane, wave, acc);
     return;
   }
+  const bool own_update = (j >= 0) && !(mode & kStepNoOwnUpdate) && !(dbg & 4);
   // ---- panel column j+1 -------------------------------------------------------------------
   const int row = lane & 31;
   const bool diag = (ti == tk);
@@ -339,7 +424,7 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
     v4d dacc[2][2];
     const double* Dg = A + lt_tile(tk, tk) * kTileElems;
     tile_load_acc(Dg, lane, dacc);
-    if (j >= 0 && !(dbg & 4)) {
+    if (own_update) {
       const double* Lk = A + lt_tile(tk, j) * kTileElems;
       tile_syrk_sub(Lk, Lk, lane, dacc);
     }
@@ -348,7 +433,7 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
     // this workgroup's own updated tile -> s_X
     v4d acc[2][2];
     tile_load_acc(C, lane, acc);
-    if (j >= 0 && !(dbg & 4)) tile_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, acc);
+    if (own_update) tile_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, acc);
     tile_store_acc(&s_X[0][0], kTile + 1, lane, acc);
   }
   __syncthreads();
@@ -491,10 +576,29 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   if (nt <= 0) return;
   double* LinvT = work;
   double* zbuf = work + (size_t)nt * kTileElems;
-  for (int j = -1; j <= nt - 2; ++j) {
-    const int rows = nt - j;      // ti in [j+1, nt]
-    const int cols = (j < 0) ? 1 : nt - 1 - j;  // tk in [j+1, nt-1]; the first step only factors column 0
-    hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(128), 0, s, A, LinvT, nt, j, fail, g_dbg_flags);
+  // Outer panels of NB tile columns.  Inside a panel the plain right-looking steps run on the panel's
+  // columns only; the tiles to the right then receive the whole panel in one launch (their load / store is
+  // paid once per NB columns).  Up to 64 tile columns the matrix is one panel: exactly the plain algorithm.
+  int NB = (nt <= 64) ? nt : 8;
+  if (const char* e = std::getenv("MPSFM_CHOL_NB")) { const int v = std::atoi(e); if (v > 0) NB = v; }
+  bool big_kernel = true;  // MPSFM_CHOL_BIG=0: per-tile workgroups for the panel's trailing update (A/B measurements)
+  if (const char* e = std::getenv("MPSFM_CHOL_BIG")) big_kernel = std::atoi(e) != 0;
+  for (int p0 = 0; p0 < nt; p0 += NB) {
+    const int pend = (p0 + NB - 1 < nt - 1) ? p0 + NB - 1 : nt - 1;
+    // factor column p0 (its tiles already hold every earlier column); ti in [p0, nt]
+    hipLaunchKernelGGL(k_chol_step, dim3(nt - p0 + 1, 1), dim3(128), 0, s, A, LinvT, nt, p0 - 1, fail, g_dbg_flags, p0 - 1, p0,
+                       kStepNoOwnUpdate);
+    for (int j = p0; j <= pend - 1; ++j)  // apply column j to columns (j, pend], factor column j+1; ti in [j+1, nt]
+      hipLaunchKernelGGL(k_chol_step, dim3(nt - j, pend - j), dim3(128), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0);
+    if (pend < nt - 1) {                  // columns (pend, nt-1] receive the panel p0..pend; ti in [pend+1, nt]
+      if (big_kernel) {
+        const int rows = nt - pend, cols = nt - 1 - pend;
+        hipLaunchKernelGGL(k_big_update, dim3((rows + 1) / 2, (cols + 1) / 2), dim3(256), 0, s, A, nt, pend, p0);
+      } else {
+        hipLaunchKernelGGL(k_chol_step, dim3(nt - pend, nt - 1 - pend), dim3(128), 0, s, A, LinvT, nt, pend, fail, g_dbg_flags, p0, nt - 1,
+                           kStepBig);
+      }
+    }
   }
   hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
   for (int t1 = nt; t1 > 0; t1 -= kBsG) {

@@ -424,3 +424,25 @@ def test_full_size_properties_large_configs(name):
     np.testing.assert_allclose(ang[pick], a_o, rtol=0, atol=1e-11)
     np.testing.assert_allclose(err[idx], e_o, rtol=1e-9, atol=1e-11)  # reprojection errors are per track element
     np.testing.assert_array_equal(front[idx], f_o)                      # so are the cheirality flags
+
+
+@pytest.mark.parametrize("nb", [1, 2, 3, 5])
+def test_outer_panel_cholesky_matches_oracle(nb, monkeypatch):
+    """The dense factorisation in outer panels of `nb` tile columns (used by default above 64 tile columns, forced here
+    through MPSFM_CHOL_NB on a 9-tile system): same LM trajectory as the oracle, same dense solution as the plain path."""
+    prob, _ = make_scene(48, 5000, True, seed=61)
+    with capi.BAHandle(prob.copy()) as h:
+        h.sweep_once(1e4)
+        h.dense_solve_once()
+        y_plain = h.dense_solution()
+    monkeypatch.setenv("MPSFM_CHOL_NB", str(nb))
+    with capi.BAHandle(prob.copy()) as h:
+        assert (h.reduced_dim + 31) // 32 == 9
+        h.sweep_once(1e4)
+        h.dense_solve_once()
+        y_nb = h.dense_solution()
+    np.testing.assert_allclose(y_nb, y_plain, rtol=1e-9, atol=1e-12 * np.abs(y_plain).max())
+    pg, po = prob.copy(), prob.copy()
+    sg, so = capi.ba_solve(pg), O.solve(po)
+    assert sg["num_iterations"] == so["num_iterations"] and sg["termination"] == so["termination"]
+    assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
