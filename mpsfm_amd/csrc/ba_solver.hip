@@ -38,7 +38,7 @@ void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const d
                        const int32_t* intr_idx = nullptr, double* camtab2 = nullptr);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t);
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov = nullptr);
 
 thread_local std::string g_err;
 extern int g_dbg_flags;  // dense_chol.hip: bits 0-7 dense-solve ablations, bits 8-15 track-sweep ablations
@@ -160,6 +160,7 @@ using namespace mpsfm;
 struct mpsfm_ba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
+  DenseOverlap ov;  // second stream for the dense factorisation of large systems (nt > 64)
   bool own_stream = false;
   mpsfm_ba_options opt{};
   LossParams loss{};
@@ -215,6 +216,9 @@ static void free_handle(mpsfm_ba_handle* h) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->ov.evF) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->ov.evB) if (e) (void)hipEventDestroy(e);
+  if (h->ov.s2) (void)hipStreamDestroy(h->ov.s2);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -797,6 +801,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
   if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
   for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+  if (h->nt > 64 || std::getenv("MPSFM_CHOL_NB")) {  // the environment override lets tests run the look-ahead on small systems
+    HIP_TRY(hipStreamCreateWithFlags(&h->ov.s2, hipStreamNonBlocking));
+    for (auto& e : h->ov.evF) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : h->ov.evB) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   HIP_TRY(hipMemset(h->d_ps, 0, nps * 3 * sizeof(double)));
   HIP_TRY(hipMemset(h->d_yc, 0, (size_t)std::max(h->n, 1) * sizeof(double)));
   init_tile_tables(h->stream);
@@ -911,7 +920,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
     AssembleArgs as{h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
                     h->opt.max_lm_diagonal, h->d_A};
     launch_assemble(as, s);
-    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s);
+    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, h->ov.s2 ? &h->ov : nullptr);
   }
   return 0;
 }

@@ -231,6 +231,13 @@ struct CostArgs {
   LossParams loss;
   double* part;  // [gridDim.x][4]: reproj cost, depth cost, bad
 };
+// second stream + events for the outer-panel look-ahead of the dense factorisation (dense_chol.hip)
+struct DenseOverlap {
+  hipStream_t s2 = nullptr;
+  hipEvent_t evF[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t evB[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
 struct AssembleArgs {
   const double* Sblk; const double* gc; const double* wv; const double* diagU;
   int32_t ncv, n, nt;

@@ -334,15 +334,15 @@ __device__ __forceinline__ void tile_syrk_sub_lds(const double* At, const double
         acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void k_big_update(double* A, int nt, int j, int c0) {
+// Columns [tk0, tk_hi] of the trailing matrix (all rows ti >= tk up to the rhs row nt) receive panel columns c0..j.
+__global__ __launch_bounds__(256) void k_big_update(double* A, int nt, int j, int c0, int tk0, int tk_hi) {
   __shared__ __attribute__((aligned(16))) double s_t[2][4][kTile * kLdsLd];
   const int bx = blockIdx.x, by = blockIdx.y;
   if (bx < by) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tk0 = j + 1;
   const int ti0 = tk0 + 2 * bx, tkb = tk0 + 2 * by;
   const int ti = ti0 + (wave & 1), tk = tkb + (wave >> 1);
-  const bool valid = (ti <= nt) && (tk <= nt - 1) && (ti >= tk);
+  const bool valid = (ti <= nt) && (tk <= tk_hi) && (ti >= tk);
   // staging: thread -> (tile t, 16-byte piece q); 4 tiles x 512 pieces, 8 pieces per thread
   double2 pre[8];
   auto fetch = [&](int c) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_big_update(double* A, int nt, int j, in
     for (int u = 0; u < 8; ++u) {
       const int idx = tid + 256 * u, t = idx >> 9, q = idx & 511;
       const int trow = (t < 2) ? ti0 + t : tkb + (t - 2);
-      const bool ok = (t < 2) ? (trow <= nt) : (trow <= nt - 1);
+      const bool ok = (t < 2) ? (trow <= nt) : (trow <= tk_hi);
       pre[u] = ok ? reinterpret_cast<const double2*>(A + lt_tile(trow, c) * kTileElems)[q] : make_double2(0.0, 0.0);
     }
   };
@@ -572,7 +572,16 @@ void launch_assemble(const AssembleArgs& a, hipStream_t s) {
 
 // factor + forward substitution (steps -1 .. nt-2) and back substitution.
 // work: nt*1024 doubles for L^-T of the diagonal tiles followed by nt*32 doubles for z.
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s) {
+static void launch_big(double* A, int nt, int j, int c0, int tk_lo, int tk_hi, hipStream_t s) {
+  if (tk_hi < tk_lo) return;
+  const int rows = nt - tk_lo + 1, cols = tk_hi - tk_lo + 1;
+  hipLaunchKernelGGL(k_big_update, dim3((rows + 1) / 2, (cols + 1) / 2), dim3(256), 0, s, A, nt, j, c0, tk_lo, tk_hi);
+}
+
+// ov (may be NULL): a second stream and events.  With it the update of an outer panel is split: the tile
+// columns of the NEXT panel are updated on the main stream (the factorisation needs them next), the columns
+// beyond run on the second stream under the next panel's factorisation steps.
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov) {
   if (nt <= 0) return;
   double* LinvT = work;
   double* zbuf = work + (size_t)nt * kTileElems;
@@ -583,22 +592,45 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   if (const char* e = std::getenv("MPSFM_CHOL_NB")) { const int v = std::atoi(e); if (v > 0) NB = v; }
   bool big_kernel = true;  // MPSFM_CHOL_BIG=0: per-tile workgroups for the panel's trailing update (A/B measurements)
   if (const char* e = std::getenv("MPSFM_CHOL_BIG")) big_kernel = std::atoi(e) != 0;
-  for (int p0 = 0; p0 < nt; p0 += NB) {
+  bool overlap = ov && ov->s2 && big_kernel && NB < nt;
+  if (const char* e = std::getenv("MPSFM_CHOL_OVERLAP")) overlap = overlap && std::atoi(e) != 0;
+  int npanel = 0;
+  bool b_pending = false;  // an update on the second stream has been recorded in ov->evB and not yet waited for
+  for (int p0 = 0; p0 < nt; p0 += NB, ++npanel) {
     const int pend = (p0 + NB - 1 < nt - 1) ? p0 + NB - 1 : nt - 1;
     // factor column p0 (its tiles already hold every earlier column); ti in [p0, nt]
     hipLaunchKernelGGL(k_chol_step, dim3(nt - p0 + 1, 1), dim3(128), 0, s, A, LinvT, nt, p0 - 1, fail, g_dbg_flags, p0 - 1, p0,
                        kStepNoOwnUpdate);
     for (int j = p0; j <= pend - 1; ++j)  // apply column j to columns (j, pend], factor column j+1; ti in [j+1, nt]
       hipLaunchKernelGGL(k_chol_step, dim3(nt - j, pend - j), dim3(128), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0);
-    if (pend < nt - 1) {                  // columns (pend, nt-1] receive the panel p0..pend; ti in [pend+1, nt]
-      if (big_kernel) {
-        const int rows = nt - pend, cols = nt - 1 - pend;
-        hipLaunchKernelGGL(k_big_update, dim3((rows + 1) / 2, (cols + 1) / 2), dim3(256), 0, s, A, nt, pend, p0);
+    if (pend >= nt - 1) break;
+    // columns (pend, nt-1] receive the panel p0..pend; ti in [pend+1, nt]
+    if (!big_kernel) {
+      hipLaunchKernelGGL(k_chol_step, dim3(nt - pend, nt - 1 - pend), dim3(128), 0, s, A, LinvT, nt, pend, fail, g_dbg_flags, p0, nt - 1,
+                         kStepBig);
+    } else if (!overlap) {
+      launch_big(A, nt, pend, p0, pend + 1, nt - 1, s);
+    } else {
+      const int qend = (pend + NB < nt - 1) ? pend + NB : nt - 1;  // last column of the next panel
+      hipEvent_t evF = ov->evF[npanel & 3], evB = ov->evB[npanel & 3];
+      (void)hipEventRecord(evF, s);                                  // panel p0..pend is final
+      // next panel's columns on the main stream; they were last written by the previous second-stream update
+      if (b_pending) (void)hipStreamWaitEvent(s, ov->evB[(npanel - 1) & 3], 0);
+      launch_big(A, nt, pend, p0, pend + 1, qend, s);
+      // the columns beyond, concurrently with the next panel's steps (disjoint tile columns)
+      if (qend < nt - 1) {
+        (void)hipStreamWaitEvent(ov->s2, evF, 0);
+        launch_big(A, nt, pend, p0, qend + 1, nt - 1, ov->s2);
+        (void)hipEventRecord(evB, ov->s2);
+        b_pending = true;
       } else {
-        hipLaunchKernelGGL(k_chol_step, dim3(nt - pend, nt - 1 - pend), dim3(128), 0, s, A, LinvT, nt, pend, fail, g_dbg_flags, p0, nt - 1,
-                           kStepBig);
+        b_pending = false;
       }
     }
+  }
+  if (overlap && npanel > 0) {
+    // everything queued on the second stream must be complete before the substitution (and the next assemble)
+    for (int k = 0; k < 4; ++k) (void)hipStreamWaitEvent(s, ov->evB[k], 0);
   }
   hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
   for (int t1 = nt; t1 > 0; t1 -= kBsG) {
