@@ -144,6 +144,19 @@ def main():
         except Exception:  # noqa: BLE001
             pass
 
+    # matrix-pipe utilisation of the factorisation kernel from the committed counter pass (profiles/rNN_pmc_mfma.json:
+    # SQ_VALU_MFMA_BUSY_CYCLES over the chip's SIMD-cycles while the kernel ran); null if absent
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))
+    if cands:
+        try:
+            mf = json.load(open(cands[-1]))
+            ks = (mf.get("bench_C3") or {}).get("mpsfm::k_chol_step")
+            if ks:
+                roof_dense["mfma_util_pmc"] = ks.get("mfma_util")
+                roof_dense["mfma_util_source"] = os.path.basename(cands[-1])
+        except Exception:  # noqa: BLE001
+            pass
+
     out = {
         "metric": "BA residual-evals/sec (LM iterations/sec alongside), 200 imgs / 150k pts prior-BA",
         "value": revals / dt,

@@ -801,7 +801,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
   if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
   for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
-  if (h->nt > 64 || std::getenv("MPSFM_CHOL_NB")) {  // the environment override lets tests run the look-ahead on small systems
+  // tuning / test overrides of the dense factorisation, read once per handle
+  if (const char* e = std::getenv("MPSFM_CHOL_NB")) h->ov.nb = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("MPSFM_CHOL_BIG")) h->ov.big = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MPSFM_CHOL_OVERLAP")) h->ov.overlap = std::atoi(e) != 0;
+  if (h->nt > 64 || h->ov.nb > 0) {
     HIP_TRY(hipStreamCreateWithFlags(&h->ov.s2, hipStreamNonBlocking));
     for (auto& e : h->ov.evF) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : h->ov.evB) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -920,7 +924,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
     AssembleArgs as{h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
                     h->opt.max_lm_diagonal, h->d_A};
     launch_assemble(as, s);
-    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, h->ov.s2 ? &h->ov : nullptr);
+    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov);
   }
   return 0;
 }

@@ -233,6 +233,9 @@ struct CostArgs {
 };
 // second stream + events for the outer-panel look-ahead of the dense factorisation (dense_chol.hip)
 struct DenseOverlap {
+  int nb = 0;            // outer panel width in tile columns; 0: default (one panel up to 64 tile columns, else 8)
+  bool big = true;       // LDS-staged 64x64 trailing update (false: per-tile workgroups, for A/B measurements)
+  bool overlap = true;   // second-stream look-ahead
   hipStream_t s2 = nullptr;
   hipEvent_t evF[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t evB[4] = {nullptr, nullptr, nullptr, nullptr};

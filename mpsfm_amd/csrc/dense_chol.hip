@@ -6,8 +6,6 @@
 // row-major inside a tile.  Tile row `nt` (one extra) carries the right-hand side in its row 0, so
 // the forward substitution z = L^-1 rhs falls out of the factorisation; k_backsub then solves
 // L^T y = z.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace mpsfm {
@@ -589,11 +587,9 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   // columns only; the tiles to the right then receive the whole panel in one launch (their load / store is
   // paid once per NB columns).  Up to 64 tile columns the matrix is one panel: exactly the plain algorithm.
   int NB = (nt <= 64) ? nt : 8;
-  if (const char* e = std::getenv("MPSFM_CHOL_NB")) { const int v = std::atoi(e); if (v > 0) NB = v; }
-  bool big_kernel = true;  // MPSFM_CHOL_BIG=0: per-tile workgroups for the panel's trailing update (A/B measurements)
-  if (const char* e = std::getenv("MPSFM_CHOL_BIG")) big_kernel = std::atoi(e) != 0;
-  bool overlap = ov && ov->s2 && big_kernel && NB < nt;
-  if (const char* e = std::getenv("MPSFM_CHOL_OVERLAP")) overlap = overlap && std::atoi(e) != 0;
+  if (ov && ov->nb > 0) NB = ov->nb;
+  const bool big_kernel = !ov || ov->big;
+  const bool overlap = ov && ov->s2 && ov->overlap && big_kernel && NB < nt;
   int npanel = 0;
   bool b_pending = false;  // an update on the second stream has been recorded in ov->evB and not yet waited for
   for (int p0 = 0; p0 < nt; p0 += NB, ++npanel) {

@@ -56,6 +56,38 @@ try:
 except Exception as e:  # noqa: BLE001
     res["error"] = repr(e)
 json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+
+# ---- MFMA counters of the dense-solve kernels: busy cycles are summed over the SIMDs of the chip
+def mfma_summary(d):
+    f = find(d, "*counter_collection.csv")
+    if not f:
+        return None
+    acc = defaultdict(lambda: defaultdict(float))
+    dur = defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if not any(t in k for t in ("k_chol_step", "k_big_update", "k_backsub_group")):
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    out = {}
+    for k, c in acc.items():
+        ns = float(sum(dur[k].values()))
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0)           # summed over the 8 XCDs
+        busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)  # summed over the SIMDs: 64 cycles per v_mfma_f64_16x16x4_f64
+        insts = c.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
+        out[k] = {"dispatches": len(dur[k]), "kernel_ns": ns, "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_INSTS_VALU_MFMA_F64": insts,
+                  "SQ_INSTS_VALU_MFMA_MOPS_F64": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0), "GRBM_GUI_ACTIVE": gui,
+                  # share of the chip's SIMD-cycles (256 CUs x 4) with the matrix pipe busy while the kernel ran
+                  "mfma_util": (busy / (gui / 8.0 * 1024.0)) if gui > 0 else None,
+                  # 2048 flops per v_mfma_f64_16x16x4_f64 wave-instruction, over the kernels' own durations
+                  "mfma_tflops": (insts * 2048.0 / (ns * 1e-9) / 1e12) if ns > 0 else None}
+    return out
+
+mf = {"tag": tag, "note": "counter passes serialise kernels (no second-stream overlap); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
+      "bench_C3": mfma_summary("pmc_mfma"), "dense_C4": mfma_summary("pmc_mfma_c4")}
+json.dump(mf, open(os.path.join(dst, f"{tag}_pmc_mfma.json"), "w"), indent=1)
+print(json.dumps({"mfma": {a: {k: (v["mfma_util"], v["mfma_tflops"]) for k, v in (b or {}).items()} for a, b in mf.items() if isinstance(b, dict)}}))
 for b in ("bench_trace.json",):
     p = os.path.join(out, b)
     if os.path.exists(p):
