@@ -1,0 +1,65 @@
+"""Randomised parity: many problem shapes against the oracle, solved one at a time and several at once on
+separate streams (the concurrent runs perturb kernel scheduling: workgroups of a launch start late, launches of
+different handles interleave — the conditions under which a latent ordering bug would show)."""
+
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from mpsfm_amd import capi
+from mpsfm_amd.synthetic import make_scene
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_problem(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_cams = int(rng.integers(3, 72))
+    n_pts = int(rng.integers(40, 5000))
+    with_depth = bool(rng.integers(0, 2))
+    max_track = int(rng.choice([4, 12, 30, 70]))          # 70 > 64 local cameras: the long-track kernels
+    prob, _ = make_scene(n_cams, n_pts, with_depth, seed=seed, outlier_frac=float(rng.choice([0.0, 0.05, 0.2])), max_track=max_track)
+    # random constant landmarks and cameras (besides the gauge camera), sometimes a duplicated observation
+    if rng.random() < 0.5:
+        prob.pt_const[rng.random(prob.n_pts) < 0.1] = 1
+    if rng.random() < 0.4 and n_cams > 4:
+        prob.pose_const[rng.choice(np.arange(2, n_cams), size=max(1, n_cams // 6), replace=False)] = 1
+    if rng.random() < 0.3 and prob.n_obs > 10:
+        k = rng.choice(prob.n_obs, 5, replace=False)
+        prob.obs_cam = np.concatenate([prob.obs_cam, prob.obs_cam[k]]).astype(np.int32)
+        prob.obs_pt = np.concatenate([prob.obs_pt, prob.obs_pt[k]]).astype(np.int32)
+        prob.obs_xy = np.concatenate([prob.obs_xy, prob.obs_xy[k] + rng.normal(0, 0.5, (5, 2))])
+    if rng.random() < 0.3:
+        prob.reproj_loss_type = int(rng.integers(0, 3))
+    return prob
+
+
+def _check(seed, sg, pg):
+    po = _random_problem(seed)
+    so = O.solve(po)
+    assert sg["initial_cost"] == pytest.approx(so["initial_cost"], rel=1e-11), seed
+    assert sg["termination"] == so["termination"], seed
+    assert abs(sg["num_iterations"] - so["num_iterations"]) <= 1, seed   # a tolerance test may fall either side by rounding
+    assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-6), seed
+    if sg["num_iterations"] == so["num_iterations"]:
+        assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8), seed
+        np.testing.assert_allclose(pg.cam_t, po.cam_t, atol=1e-5, err_msg=str(seed))
+
+
+@pytest.mark.timeout(900)
+def test_random_problems_one_by_one():
+    for seed in range(16):
+        pg = _random_problem(seed)
+        _check(seed, capi.ba_solve(pg), pg)
+
+
+@pytest.mark.timeout(900)
+def test_random_problems_concurrently():
+    seeds = list(range(16, 40))
+    probs = {s: _random_problem(s) for s in seeds}
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        sums = dict(zip(seeds, ex.map(lambda s: capi.ba_solve(probs[s]), seeds)))
+    for s in seeds:
+        _check(s, sums[s], probs[s])
