@@ -20,8 +20,18 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+FLAGS_STAMP = os.path.join(HERE, "build", "extra_flags.txt")
+
+
+def _flags_changed() -> bool:
+    """True when MPSFM_EXTRA_FLAGS differs from what the existing objects were compiled with."""
+    want = os.environ.get("MPSFM_EXTRA_FLAGS", "").strip()
+    have = open(FLAGS_STAMP).read().strip() if os.path.exists(FLAGS_STAMP) else ""
+    return want != have
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or _flags_changed():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -31,6 +41,7 @@ def is_stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
+    force = force or _flags_changed()  # other flags: every object is rebuilt
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=default", "-Wall", "-Wno-unused-function"]
@@ -58,6 +69,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(os.environ.get("MPSFM_EXTRA_FLAGS", "").strip())
     return LIB
 
 

@@ -737,6 +737,13 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   }
 
   lap("chunks + pair tables");
+  if (h->opt.verbose >= 2 && !chunks.empty()) {
+    double sr = 0, sp = 0, sc = 0, sb = 0, se = 0; int mb = 0, mc = 0;
+    for (const ChunkHdr& H : chunks) { sr += H.nrec; sp += H.npt; sc += H.ncam; sb += H.nblk; se += H.nent; mb = std::max(mb, H.nblk); mc = std::max(mc, H.ncam); }
+    const double n = (double)chunks.size();
+    std::fprintf(stderr, "[mpsfm_ba] build: %zu chunks; per chunk: %.1f records, %.1f landmarks, %.1f cameras (max %d), %.1f work items (max %d), %.1f pairs\n",
+                 chunks.size(), sr / n, sp / n, sc / n, mc, sb / n, mb, se / n);
+  }
   // -- fixed records (landmark index re-ordered)
   std::vector<int32_t> fx_cam, fx_pt; std::vector<uint32_t> fx_meta; std::vector<double> fx_xy, fx_d, fx_m, fx_a;
   for (size_t i = 0; i < fixed.size(); ++i) {
