@@ -14,7 +14,7 @@ namespace mpsfm {
 #define MPSFM_TILE_CAMS 16
 #endif
 #ifndef MPSFM_ITEM_PAIRS
-#define MPSFM_ITEM_PAIRS 16
+#define MPSFM_ITEM_PAIRS 64
 #endif
 #ifndef MPSFM_ENT_STAGE
 #define MPSFM_ENT_STAGE 1024

@@ -45,7 +45,9 @@ def _check(seed, sg, pg):
     assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-6), seed
     if sg["num_iterations"] == so["num_iterations"]:
         assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8), seed
-        np.testing.assert_allclose(pg.cam_t, po.cam_t, atol=1e-5, err_msg=str(seed))
+        # a solve that runs into the iteration limit wanders along a flat valley: equal cost, poses only to ~1e-4
+        atol = 1e-3 if sg["termination"] == "max_iterations" else 1e-5
+        np.testing.assert_allclose(pg.cam_t, po.cam_t, atol=atol, err_msg=str(seed))
 
 
 @pytest.mark.timeout(900)
