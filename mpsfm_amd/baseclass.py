@@ -4,7 +4,7 @@
 
 from __future__ import annotations
 
-from time import time
+from time import perf_counter
 
 
 class Conf(dict):
@@ -36,39 +36,70 @@ def to_conf(obj) -> Conf:
     return out
 
 
+class _Stopwatch:
+    """One running interval; `log(tstart=True)` arms it, `log(tend=True)` reads it."""
+
+    def __init__(self):
+        self.t0 = None
+
+    def arm(self):
+        self.t0 = perf_counter()
+
+    def read(self) -> float:
+        if self.t0 is None:
+            raise AssertionError("log(tend=True) without a preceding log(tstart=True)")
+        return perf_counter() - self.t0
+
+
 class BaseClass:
+    """Hook order of the reference's base class (mpsfm/baseclass.py:16-29): merge the configuration, then
+    `_assert_configs`, `_propagate_conf`, `_init(*args, **kwargs)`."""
+
     freeze_conf = True
     default_conf = {"verbose": 0}
 
     def __init__(self, conf=None, *args, **kwargs):
-        default = to_conf(self.default_conf)
-        passed = to_conf(conf)
-        if self.freeze_conf:
-            unknown = [k for k in passed if k not in default]
-            if unknown:
-                raise KeyError(f"unknown configuration key(s) {unknown} for {type(self).__name__}")
-        merged = Conf(default)
-        merged.update(passed)
-        self.conf = merged
-        self._assert_configs()
-        self._propagate_conf()
+        self.conf = self._merged_conf(conf)
+        self._watch = _Stopwatch()
+        for hook in (self._assert_configs, self._propagate_conf):
+            hook()
         self._init(*args, **kwargs)
-        self.tstart = None
 
+    @classmethod
+    def _merged_conf(cls, conf) -> Conf:
+        base, given = to_conf(cls.default_conf), to_conf(conf)
+        if cls.freeze_conf:
+            extra = sorted(set(given) - set(base))
+            if extra:
+                raise KeyError(f"unknown configuration key(s) {extra} for {cls.__name__}")
+        base.update(given)
+        return base
+
+    # hooks for subclasses
     def _init(self, *args, **kwargs):
-        pass
+        return None
 
     def _assert_configs(self):
-        pass
+        return None
 
     def _propagate_conf(self):
-        pass
+        return None
+
+    @property
+    def tstart(self):
+        return self._watch.t0
 
     def log(self, *message, level=0, tstart=False, tend=False, **kwargs):
-        if self.conf.verbose >= level:
-            if tstart:
-                self.tstart = time()
-            elif tend:
-                assert len(message) == 0 and self.tstart is not None
-                message = [f"{time() - self.tstart:.3f} s"]
-            print(*message, end=" " if tstart else "\n", **kwargs)
+        """Prints when conf.verbose >= level.  tstart: print without a newline and start the stopwatch;
+        tend (no message allowed): print the elapsed seconds."""
+        if self.conf.verbose < level:
+            return
+        if tstart:
+            self._watch.arm()
+            print(*message, end=" ", **kwargs)
+            return
+        if tend:
+            if message:
+                raise AssertionError("log(tend=True) takes no message")
+            message = (f"{self._watch.read():.3f} s",)
+        print(*message, **kwargs)
