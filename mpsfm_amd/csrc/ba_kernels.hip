@@ -886,7 +886,7 @@ __global__ void k_pt_scales(int64_t n3, const uint16_t* pt_kv, const double* dia
 __global__ __launch_bounds__(kThreads) void k_cam_update(int nc, const int32_t* cam_slot, const double* q,
                                                          const double* t, const double* cs, const double* yc,
                                                          const double* gc, double* q2, double* t2, double* scal,
-                                                         const double* intr, const int32_t* intr_idx, double* camtab2) {
+                                                         const double* intr, const int32_t* intr_idx, double* camtab2, int* chol_fail) {
   __shared__ double s_red[3 * (kThreads / 64)];
   double step = 0.0, xn = 0.0, gmax = 0.0;
   for (int i = threadIdx.x; i < nc; i += kThreads) {
@@ -936,6 +936,8 @@ __global__ __launch_bounds__(kThreads) void k_cam_update(int nc, const int32_t* 
     scal[U_STEP_SQ_CAMS] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     scal[U_XN_SQ_CAMS] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     scal[U_GMAX_CAMS] = fmax(fmax(s_red[8], s_red[9]), fmax(s_red[10], s_red[11]));
+    // the factorisation's failure flag travels to the host with the other scalars and is re-armed here
+    if (chol_fail) { scal[U_CHOL_FAIL] = (double)*chol_fail; *chol_fail = 0; }
   }
 }
 
@@ -993,9 +995,9 @@ void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, in
 }
 void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs,
                        const double* yc, const double* gc, double* q2, double* t2, double* scal, hipStream_t s,
-                       const double* intr, const int32_t* intr_idx, double* camtab2) {
+                       const double* intr, const int32_t* intr_idx, double* camtab2, int* chol_fail) {
   hipLaunchKernelGGL(k_cam_update, dim3(1), dim3(kThreads), 0, s, nc, cam_slot, q, t, cs, yc, gc, q2, t2, scal, intr, intr_idx,
-                     camtab2);
+                     camtab2, chol_fail);
 }
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t s) {
   hipLaunchKernelGGL(k_pts_sqnorm, dim3(nblocks), dim3(kThreads), 0, s, np, pt_kv, pts, part);

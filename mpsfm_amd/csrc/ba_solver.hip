@@ -35,7 +35,7 @@ void launch_cam_scales(int nc, const int32_t* cam_slot, const double* cmask, con
 void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, int jacobi, double* ps, hipStream_t);
 void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs, const double* yc,
                        const double* gc, double* q2, double* t2, double* scal, hipStream_t, const double* intr = nullptr,
-                       const int32_t* intr_idx = nullptr, double* camtab2 = nullptr);
+                       const int32_t* intr_idx = nullptr, double* camtab2 = nullptr, int* chol_fail = nullptr);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
 void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov = nullptr);
@@ -807,6 +807,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_dwork, (size_t)std::max(h->nt, 1) * (1024 + 32)))) return rc;
   if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
   if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
+  HIP_TRY(hipMemset(h->d_fail, 0, sizeof(int)));
   for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
   // tuning / test overrides of the dense factorisation, read once per handle
   if (const char* e = std::getenv("MPSFM_CHOL_NB")) h->ov.nb = std::max(0, std::atoi(e));
@@ -926,7 +927,7 @@ static int run_track_sweep(mpsfm_ba_handle* h, double radius) {
 
 static int run_dense(mpsfm_ba_handle* h, double radius) {
   hipStream_t s = h->stream;
-  HIP_TRY(hipMemsetAsync(h->d_fail, 0, sizeof(int), s));
+  // d_fail is zero here: cleared at creation and re-armed by k_cam_update after every read
   if (h->n > 0) {
     AssembleArgs as{h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
                     h->opt.max_lm_diagonal, h->d_A};
@@ -1017,7 +1018,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     if (int rc = run_dense(h, radius)) return rc;
     HIP_TRY(hipEventRecord(h->ev[2], s));
     launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s,
-                      h->d_intr, h->d_intr_idx, h->d_camtab2);
+                      h->d_intr, h->d_intr_idx, h->d_camtab2, h->d_fail);
     {
       SweepArgs a = sweep_args(h, radius);
       launch_update_sweep(a, h->nchunks, s);
@@ -1028,8 +1029,6 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
       HIP_TRY(hipMemcpyAsync(h->d_scal + U_X_COST, h->d_redsc, sizeof(double) * 3, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipEventRecord(h->ev[3], s));
     HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * U_COUNT, hipMemcpyDeviceToHost, s));
-    int h_fail = 0;
-    HIP_TRY(hipMemcpyAsync(&h_fail, h->d_fail, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); sum->time_linearize_s += 1e-3 * ms;
@@ -1037,6 +1036,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); sum->time_update_s += 1e-3 * ms;
     ++n_jac_evals; ++n_cost_evals;
     const double* sc = h->h_scal;
+    const int h_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;  // set by k_chol_step, published by k_cam_update
 
     // ---- decisions (Ceres trust_region_minimizer.cc order) ------------------------------------
     x_cost = sc[U_X_COST];
@@ -1303,6 +1303,7 @@ int mpsfm_ba_dense_solve_once(mpsfm_ba_handle* h, float* elapsed_ms) {
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   if (int rc = run_dense(h, h->last_radius)) return rc;
   HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_fail, 0, sizeof(int), h->stream));  // no k_cam_update follows here to re-arm the flag
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
   float ms = 0.f;
