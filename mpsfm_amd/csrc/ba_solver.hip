@@ -6,6 +6,7 @@
 // decisions from a handful of scalars.
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <cstdio>
@@ -14,6 +15,7 @@
 #include <string>
 #include <thread>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include <sched.h>
@@ -50,12 +52,86 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     if (e_ != hipSuccess) return fail(MPSFM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// ---- caching device allocator (declared in common.h) ---------------------------------------------------
+namespace {
+struct DevCache {
+  static constexpr size_t kCap = (size_t)6 << 30;       // cached (free) bytes kept per device
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks[16];
+  std::unordered_map<void*, std::pair<size_t, int>> live;  // pointer -> (block size, device)
+  size_t cached[16] = {};
+  static size_t block_size(size_t n) {  // 1/8-of-a-power-of-two granularity: sizes that differ a little share blocks
+    n = std::max<size_t>(n, 256);
+    size_t p = 256;
+    while (p < n) p <<= 1;
+    const size_t step = std::max<size_t>(p >> 3, 256);
+    return (n + step - 1) / step * step;
+  }
+  void drop_all(int dev) {
+    for (auto& kv : free_blocks[dev]) (void)hipFree(kv.second);
+    free_blocks[dev].clear();
+    cached[dev] = 0;
+  }
+  void* alloc(size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = std::min(std::max(dev, 0), 15);
+    const size_t bs = block_size(bytes);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = free_blocks[dev].lower_bound(bs);
+    if (it != free_blocks[dev].end() && it->first <= bs + bs / 4) {
+      void* p = it->second;
+      const size_t got = it->first;
+      free_blocks[dev].erase(it);
+      cached[dev] -= got;
+      live[p] = {got, dev};
+      poison(p, got);
+      return p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bs) != hipSuccess) {
+      (void)hipGetLastError();
+      drop_all(dev);  // give the cached blocks back and try once more
+      if (hipMalloc(&p, bs) != hipSuccess) return nullptr;
+    }
+    live[p] = {bs, dev};
+    poison(p, bs);
+    return p;
+  }
+  // MPSFM_POISON=1 (tests): every block handed out is filled with 0xFF bytes (NaNs / huge indices), so a kernel
+  // that reads memory nobody initialised fails loudly instead of finding the zeros a fresh hipMalloc often has
+  static void poison(void* p, size_t n) {
+    static const bool on = [] { const char* e = std::getenv("MPSFM_POISON"); return e && std::atoi(e) != 0; }();
+    if (!on) return;
+    (void)hipMemset(p, 0xFF, n);
+    (void)hipDeviceSynchronize();
+  }
+  void release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live.find(p);
+    if (it == live.end()) { (void)hipFree(p); return; }
+    const size_t bs = it->second.first;
+    const int dev = it->second.second;
+    live.erase(it);
+    if (cached[dev] + bs > kCap) { (void)hipFree(p); return; }
+    free_blocks[dev].emplace(bs, p);
+    cached[dev] += bs;
+  }
+};
+DevCache& dev_cache() {
+  static DevCache* c = new DevCache();  // never destroyed: the HIP runtime may be gone at static-destruction time
+  return *c;
+}
+}  // namespace
+void* cached_malloc(size_t bytes) { return dev_cache().alloc(bytes); }
+void cached_free(void* p) { dev_cache().release(p); }
+
 template <typename T>
 static int dev_alloc(T** p, size_t count) {
-  *p = nullptr;
   if (count == 0) count = 1;
-  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
-  if (e != hipSuccess) return fail(MPSFM_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  *p = (T*)cached_malloc(count * sizeof(T));
+  if (!*p) return fail(MPSFM_ENOMEM, "hipMalloc failed");
   return 0;
 }
 // Uploads of caller / table memory go through a process-wide pinned staging buffer (two halves, the host copy
@@ -105,6 +181,20 @@ static Stager& stager() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   return g_stagers[(size_t)std::min(std::max(dev, 0), 15)];
+}
+
+// for the other translation units (int_kernels.hip): queue a staged upload / wait for everything queued
+int staged_upload(void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  Stager& G = stager();
+  std::lock_guard<std::mutex> lk(G.mu);
+  if (int rc = G.init()) return rc;
+  return G.push(dst, src, bytes);
+}
+int staged_drain() {
+  Stager& G = stager();
+  std::lock_guard<std::mutex> lk(G.mu);
+  return G.buf ? G.drain() : 0;
 }
 
 // staged copy of host memory to the device, complete on return
@@ -213,7 +303,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (void* p : ptrs) cached_free(p);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ov.evF) if (e) (void)hipEventDestroy(e);

@@ -231,6 +231,12 @@ struct CostArgs {
   LossParams loss;
   double* part;  // [gridDim.x][4]: reproj cost, depth cost, bad
 };
+// Caching device allocator (ba_solver.hip): hipMalloc / hipFree cost 10-300 us each and a handle makes ~60 of
+// them; freed blocks are kept per device (up to a cap) and handed out again — with whatever an earlier owner
+// left in them: every consumer initialises what it reads (MPSFM_POISON=1 fills each block with 0xFF to prove it).
+void* cached_malloc(size_t bytes);
+void cached_free(void* p);
+
 // second stream + events for the outer-panel look-ahead of the dense factorisation (dense_chol.hip)
 struct DenseOverlap {
   int nb = 0;            // outer panel width in tile columns; 0: default (one panel up to 64 tile columns, else 8)

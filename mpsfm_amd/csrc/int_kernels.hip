@@ -15,6 +15,9 @@
 namespace mpsfm {
 
 extern thread_local std::string g_err;
+// pinned staging uploads (ba_solver.hip): pageable caller memory is not handed to the runtime directly
+int staged_upload(void* dst, const void* src, size_t bytes);
+int staged_drain();
 static int ifail(int code, const std::string& m) { g_err = m; return code; }
 #define INT_TRY(expr)                                                                                \
   do {                                                                                               \
@@ -342,12 +345,23 @@ __global__ __launch_bounds__(kIT) void k_int_exp(size_t n, const double* z, doub
 }
 
 struct IntPool {
-  std::vector<void*> v;
-  ~IntPool() { for (void* p : v) if (p) (void)hipFree(p); }
+  std::vector<void*> v, vh;
+  ~IntPool() {
+    for (void* p : v) cached_free(p);
+    for (void* p : vh) if (p) (void)hipHostFree(p);
+  }
+  // pinned host memory: the per-iteration read-backs (done flags, energy partials) are plain DMA, not staged copies
+  template <typename T>
+  T* get_host(size_t n) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return nullptr;
+    vh.push_back(p);
+    return (T*)p;
+  }
   template <typename T>
   T* get(size_t n) {
-    void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    void* p = cached_malloc(std::max<size_t>(n, 1) * sizeof(T));
+    if (!p) return nullptr;
     v.push_back(p);
     return (T*)p;
   }
@@ -380,7 +394,7 @@ struct IntBatch {
   double *d_sp = nullptr, *d_out = nullptr, *d_in = nullptr, *d_K = nullptr, *d_esp = nullptr;
   uint8_t* d_valid = nullptr;
   std::vector<int32_t> act;               // host copy of the activity mask
-  std::vector<double> hpart, hstate, hesp;
+  double *hpart = nullptr, *hstate = nullptr, *hesp = nullptr;  // pinned: [B][G][8], [B][8], [B]
 };
 
 static int int_check(const mpsfm_int_problem* P, int32_t device) {
@@ -465,30 +479,34 @@ static int int_setup(const mpsfm_int_problem* Ps, int B, bool use_sparse, bool s
     D.spd = take(1); D.spb = take(1); D.r = take(1); D.zz = take(1); D.p0 = take(1); D.p1 = take(1); D.q = take(1);
   }
   // inputs: [prior | unc | init] each [B][N], then normals [B][N][3], nvar [B][N][3]
+  auto up = [&](void* dst, const void* src, size_t bytes) { return staged_upload(dst, src, bytes); };
   for (int b = 0; b < B; ++b) {
     const mpsfm_int_problem* P = &Ps[b];
-    INT_TRY(hipMemcpyAsync(d_in + (size_t)b * N, P->depth_prior, sizeof(double) * N, hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(d_in + BN + (size_t)b * N, P->depth_uncertainty, sizeof(double) * N, hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(d_in + 2 * BN + (size_t)b * N, P->depth_init, sizeof(double) * N, hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(d_in + 3 * BN + (size_t)b * 3 * N, P->normals, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(d_in + 6 * BN + (size_t)b * 3 * N, P->normals_var, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(U.d_valid + (size_t)b * N, P->valid, N, hipMemcpyHostToDevice, st));
+    if (int rc = up(d_in + (size_t)b * N, P->depth_prior, sizeof(double) * N)) return rc;
+    if (int rc = up(d_in + BN + (size_t)b * N, P->depth_uncertainty, sizeof(double) * N)) return rc;
+    if (int rc = up(d_in + 2 * BN + (size_t)b * N, P->depth_init, sizeof(double) * N)) return rc;
+    if (int rc = up(d_in + 3 * BN + (size_t)b * 3 * N, P->normals, sizeof(double) * 3 * N)) return rc;
+    if (int rc = up(d_in + 6 * BN + (size_t)b * 3 * N, P->normals_var, sizeof(double) * 3 * N)) return rc;
+    if (int rc = up(U.d_valid + (size_t)b * N, P->valid, N)) return rc;
   }
-  INT_TRY(hipMemcpyAsync(D.spd, spd.data(), sizeof(double) * BN, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(D.spb, spb.data(), sizeof(double) * BN, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(U.d_K, Kh.data(), sizeof(double) * 4 * B, hipMemcpyHostToDevice, st));
-  INT_TRY(hipMemcpyAsync(U.d_off, U.sp_off.data(), sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, st));
+  if (int rc = up(D.spd, spd.data(), sizeof(double) * BN)) return rc;
+  if (int rc = up(D.spb, spb.data(), sizeof(double) * BN)) return rc;
+  if (int rc = up(U.d_K, Kh.data(), sizeof(double) * 4 * B)) return rc;
+  if (int rc = up(U.d_off, U.sp_off.data(), sizeof(int32_t) * ((size_t)B + 1))) return rc;
   INT_TRY(hipMemsetAsync(D.p0, 0, sizeof(double) * 2 * BN, st));
   if (!ids.empty()) {
-    INT_TRY(hipMemcpyAsync(U.d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(U.d_sp, U.sprec.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
-    INT_TRY(hipMemcpyAsync(U.d_sp + ids.size(), U.sdep.data(), sizeof(double) * ids.size(), hipMemcpyHostToDevice, st));
+    if (int rc = up(U.d_ids, ids.data(), sizeof(int32_t) * ids.size())) return rc;
+    if (int rc = up(U.d_sp, U.sprec.data(), sizeof(double) * ids.size())) return rc;
+    if (int rc = up(U.d_sp + ids.size(), U.sdep.data(), sizeof(double) * ids.size())) return rc;
   }
   U.act.assign((size_t)B, 1);
-  INT_TRY(hipMemcpyAsync(U.d_act, U.act.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
-  // spd / spb / Kh are host vectors that die with this frame: the copies above must have left them
+  if (int rc = up(U.d_act, U.act.data(), sizeof(int32_t) * B)) return rc;
+  // everything staged must be on the device before the first kernel on st (and spd / spb / Kh die with this frame)
+  if (int rc = staged_drain()) return rc;
   INT_TRY(hipStreamSynchronize(st));
-  U.hpart.resize((size_t)B * G * 8); U.hstate.resize((size_t)B * 8); U.hesp.resize((size_t)B);
+  double* hblk = pool.get_host<double>((size_t)B * G * 8 + (size_t)B * 9);
+  if (!hblk) return ifail(MPSFM_ENOMEM, "hipHostMalloc failed");
+  U.hpart = hblk; U.hstate = hblk + (size_t)B * G * 8; U.hesp = U.hstate + (size_t)B * 8;
   return 0;
 }
 
@@ -522,7 +540,7 @@ static int int_run_cg(IntBatch& U, hipStream_t st, double rtol, int max_iter, in
       hipLaunchKernelGGL(k_cg_dir, grid, dim3(kIT), 0, st, D, Gc, k, k == 0 ? 1 : 0, rtol);
       hipLaunchKernelGGL(k_cg_update, grid, dim3(kIT), 0, st, D, Gc, k);
     }
-    INT_TRY(hipMemcpyAsync(U.hstate.data(), D.state, sizeof(double) * 8 * U.B, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
+    INT_TRY(hipMemcpyAsync(U.hstate, D.state, sizeof(double) * 8 * U.B, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
     done = true;
     for (int b = 0; b < U.B; ++b)
       if (U.act[(size_t)b]) {
@@ -585,13 +603,13 @@ extern "C" int mpsfm_integrate_depth_batch(int32_t n_images, const mpsfm_int_pro
     hipLaunchKernelGGL(k_int_weights, grid, dim3(kIT), 0, st, D, P->k, P->lambda1, (const int32_t*)U.d_keep);
     hipLaunchKernelGGL(k_int_sparse_energy, dim3(B), dim3(kIT), 0, st, D, (const int32_t*)U.d_off, (const int32_t*)U.d_ids, (const double*)U.d_sp,
                        (const double*)(U.d_sp + U.ids.size()), P->lambda2, U.d_esp);
-    INT_TRY(hipMemcpyAsync(U.hpart.data(), D.part, sizeof(double) * U.hpart.size(), hipMemcpyDeviceToHost, st));
-    INT_TRY(hipMemcpyAsync(U.hesp.data(), U.d_esp, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    INT_TRY(hipMemcpyAsync(U.hpart, D.part, sizeof(double) * (size_t)B * U.G * 8, hipMemcpyDeviceToHost, st));
+    INT_TRY(hipMemcpyAsync(U.hesp, U.d_esp, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     INT_TRY(hipStreamSynchronize(st));
     for (int b = 0; b < B; ++b) {
       if (!U.act[(size_t)b]) continue;
       double e_n = 0.0, e_d = 0.0;
-      const double* hp = U.hpart.data() + (size_t)b * U.G * 8;
+      const double* hp = U.hpart + (size_t)b * U.G * 8;
       for (int i = 0; i < U.G; ++i) { e_n += hp[(size_t)i * 8]; e_d += hp[(size_t)i * 8 + 1]; }
       const bool has_sparse = U.sp_off[(size_t)b + 1] > U.sp_off[(size_t)b];
       en[(size_t)b] = e_n + e_d + (has_sparse ? U.hesp[(size_t)b] : 0.0);

@@ -24,11 +24,12 @@ static int tfail(int code, const std::string& m) { g_err = m; return code; }
 
 struct DevBuf {
   std::vector<void*> ptrs;
-  ~DevBuf() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+  ~DevBuf() { for (void* p : ptrs) cached_free(p); }
   template <typename T>
   T* up(const T* host, size_t n, bool copy = true) {
     void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    p = cached_malloc(std::max<size_t>(n, 1) * sizeof(T));
+    if (!p) return nullptr;
     ptrs.push_back(p);
     if (copy && n && host) (void)hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice);
     return (T*)p;
