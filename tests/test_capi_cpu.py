@@ -49,3 +49,34 @@ def test_invalid_problem_is_rejected_before_touching_the_device():
     with pytest.raises(capi.MpsfmHipError) as e:
         capi.ba_solve(prob)
     assert e.value.code == -1
+
+
+def test_integration_entry_points_validate_arguments_first():
+    """Argument errors of the depth-integration entry points are reported as MPSFM_EINVAL before any device is
+    touched; an empty batch is a no-op; without a device the calls fail loudly (MPSFM_ENODEVICE)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from mpsfm_amd.synthetic_maps import make_maps
+
+    L = capi.lib()
+    L.mpsfm_integrate_depth_batch.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    assert L.mpsfm_integrate_depth_batch(0, None, 0, None, None) == 0
+    assert L.mpsfm_integrate_depth_batch(-1, None, 0, None, None) == -1
+    assert L.mpsfm_integrate_depth_batch(2, None, 0, None, None) == -1
+    assert capi.integrate_depth_batch([]) == []
+    m = make_maps(12, 16, seed=0, n_sparse=5)
+    nu = m["normals_uncertainty"]
+    nvar = np.stack([nu[..., 0, 0], nu[..., 1, 1], nu[..., 2, 2]], -1)
+    args = (m["depth_prior"], m["depth_uncertainty"], m["valid"], m["normals"], nvar, m["depth_init"], m["K"])
+    with pytest.raises(capi.MpsfmHipError) as e:
+        capi.integration_variances(*args, np.array([[1, 1]]), rtol=0.0)
+    assert e.value.code == -1
+    if capi.device_count() == 0:
+        with pytest.raises(capi.MpsfmHipError) as e:
+            capi.integration_variances(*args, np.array([[1, 1]]))
+        assert e.value.code == -2
+        with pytest.raises(capi.MpsfmHipError) as e:
+            capi.integrate_depth(*args, m["kps"], m["depth3d"], m["zvars3d"])
+        assert e.value.code == -2
