@@ -178,7 +178,26 @@ def dense_lm(prob: BAProblem):
                 final_cost=x_cost, cam_quat=q.numpy(), cam_t=t.numpy(), pts=X.numpy())
 
 
+def dense_point_covs(prob: BAProblem):
+    """Covariance of every landmark given everything else: inverse of k * sum_obs Jp^T Jp with Jp = d(reprojection) /
+    d(point) by forward-mode differentiation (trivial loss scaled by the magnitude, as the oracle documents)."""
+    q, t, X = torch.tensor(prob.cam_quat), torch.tensor(prob.cam_t), torch.tensor(prob.pts)
+    K = torch.tensor(prob.cam_intr[prob.cam_intr_idx])
+    oc, op = torch.tensor(prob.obs_cam, dtype=torch.long), torch.tensor(prob.obs_pt, dtype=torch.long)
+    xy = torch.tensor(prob.obs_xy)
+
+    def one(qc, tc, Kc, Xp, uv):
+        return t_reproj(qc[None], torch.zeros(1, 3), tc[None], Kc[None], Xp[None], uv[None])[0]
+
+    Jp = torch.func.vmap(torch.func.jacfwd(one, argnums=3))(q[oc], t[oc], K[oc], X[op], xy)      # [n_obs, 2, 3]
+    H = torch.zeros(prob.n_pts, 3, 3).index_add(0, op, prob.reproj_loss_magnitude * Jp.transpose(1, 2) @ Jp)
+    return torch.linalg.inv(H).numpy()
+
+
 if __name__ == "__main__":
+    covs = dense_point_covs(load("scene_4x120_reproj"))
+    np.savez_compressed(os.path.join(HERE, "point_covs_scene_4x120_reproj.npz"), covs=covs)
+    print("point covariances:", covs.shape, "trace range", np.trace(covs, axis1=1, axis2=2).min(), np.trace(covs, axis1=1, axis2=2).max())
     for name in ("scene_2x20", "scene_5x200", "scene_4x120_reproj"):
         out = dense_lm(load(name))
         print(f"{name}: {out['num_iterations']} iterations, {out['termination']}, cost {out['trace_cost'][0]:.10g} -> {out['final_cost']:.10g}")

@@ -95,3 +95,12 @@ def test_lm_trajectory_matches_independent_dense_implementation(name):
     np.testing.assert_allclose(prob.cam_quat, g["cam_quat"], atol=1e-11)
     np.testing.assert_allclose(prob.cam_t, g["cam_t"], atol=1e-11)
     np.testing.assert_allclose(prob.pts, g["pts"], atol=1e-10)
+
+
+def test_point_covariances_match_autograd_golden():
+    import os
+
+    g = np.load(os.path.join(GOLDEN, "point_covs_scene_4x120_reproj.npz"))["covs"]
+    prob = load_scene("scene_4x120_reproj")[0]
+    c = O.point_covs(prob)
+    np.testing.assert_allclose(c, g, rtol=1e-9, atol=1e-12 * np.abs(g).max())
