@@ -127,6 +127,57 @@ DevCache& dev_cache() {
 void* cached_malloc(size_t bytes) { return dev_cache().alloc(bytes); }
 void cached_free(void* p) { dev_cache().release(p); }
 
+// Streams, events and the small pinned scalar block of a handle are recycled the same way: creating and
+// destroying them costs more than a whole solve of a small problem.  Per device; never destroyed.
+namespace {
+struct HandleResources {
+  std::mutex mu;
+  std::vector<hipStream_t> streams[16];
+  std::vector<hipEvent_t> timing_events[16], plain_events[16];
+  std::vector<void*> pinned[16];  // blocks of kPinnedBytes
+  static constexpr size_t kPinnedBytes = 512;
+  static int dev() { int d = 0; (void)hipGetDevice(&d); return std::min(std::max(d, 0), 15); }
+};
+HandleResources& pool() { static HandleResources* r = new HandleResources(); return *r; }
+}  // namespace
+hipError_t pooled_stream(hipStream_t* s) {
+  HandleResources& R = pool();
+  { std::lock_guard<std::mutex> lk(R.mu); auto& v = R.streams[R.dev()]; if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; } }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+void release_stream(hipStream_t s) {
+  if (!s) return;
+  HandleResources& R = pool();
+  std::lock_guard<std::mutex> lk(R.mu);
+  R.streams[R.dev()].push_back(s);
+}
+static hipError_t pooled_event(hipEvent_t* e, bool timing) {
+  HandleResources& R = pool();
+  {
+    std::lock_guard<std::mutex> lk(R.mu);
+    auto& v = timing ? R.timing_events[R.dev()] : R.plain_events[R.dev()];
+    if (!v.empty()) { *e = v.back(); v.pop_back(); return hipSuccess; }
+  }
+  return timing ? hipEventCreate(e) : hipEventCreateWithFlags(e, hipEventDisableTiming);
+}
+static void release_event(hipEvent_t e, bool timing) {
+  if (!e) return;
+  HandleResources& R = pool();
+  std::lock_guard<std::mutex> lk(R.mu);
+  (timing ? R.timing_events[R.dev()] : R.plain_events[R.dev()]).push_back(e);
+}
+static hipError_t pooled_pinned(void** p) {
+  HandleResources& R = pool();
+  { std::lock_guard<std::mutex> lk(R.mu); auto& v = R.pinned[R.dev()]; if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; } }
+  return hipHostMalloc(p, HandleResources::kPinnedBytes, hipHostMallocDefault);
+}
+static void release_pinned(void* p) {
+  if (!p) return;
+  HandleResources& R = pool();
+  std::lock_guard<std::mutex> lk(R.mu);
+  R.pinned[R.dev()].push_back(p);
+}
+
 template <typename T>
 static int dev_alloc(T** p, size_t count) {
   if (count == 0) count = 1;
@@ -304,12 +355,12 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl};
   for (void* p : ptrs) cached_free(p);
-  if (h->h_scal) (void)hipHostFree(h->h_scal);
-  for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
-  for (auto& e : h->ov.evF) if (e) (void)hipEventDestroy(e);
-  for (auto& e : h->ov.evB) if (e) (void)hipEventDestroy(e);
-  if (h->ov.s2) (void)hipStreamDestroy(h->ov.s2);
-  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  release_pinned(h->h_scal);
+  for (auto& e : h->ev) release_event(e, true);
+  for (auto& e : h->ov.evF) release_event(e, false);
+  for (auto& e : h->ov.evB) release_event(e, false);
+  release_stream(h->ov.s2);
+  if (h->own_stream) release_stream(h->stream);
   delete h;
 }
 
@@ -891,22 +942,23 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_part2, (size_t)std::max(h->nchunks + h->nlong, 1) * 8))) return rc;
   if ((rc = dev_alloc(&h->d_scal, (size_t)U_COUNT))) return rc;
   if ((rc = dev_alloc(&h->d_costpart, (size_t)1024 * 4))) return rc;
-  HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * U_COUNT * 2, hipHostMallocDefault));
+  static_assert(sizeof(double) * U_COUNT * 2 <= HandleResources::kPinnedBytes, "pinned scalar block too small");
+  HIP_TRY(pooled_pinned((void**)&h->h_scal));
   const size_t ntiles = (size_t)(h->nt + 1) * (h->nt + 2) / 2;
   if ((rc = dev_alloc(&h->d_A, ntiles * 1024))) return rc;
   if ((rc = dev_alloc(&h->d_dwork, (size_t)std::max(h->nt, 1) * (1024 + 32)))) return rc;
   if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
   if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
   HIP_TRY(hipMemset(h->d_fail, 0, sizeof(int)));
-  for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+  for (auto& e : h->ev) HIP_TRY(pooled_event(&e, true));
   // tuning / test overrides of the dense factorisation, read once per handle
   if (const char* e = std::getenv("MPSFM_CHOL_NB")) h->ov.nb = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("MPSFM_CHOL_BIG")) h->ov.big = std::atoi(e) != 0;
   if (const char* e = std::getenv("MPSFM_CHOL_OVERLAP")) h->ov.overlap = std::atoi(e) != 0;
   if (h->nt > 64 || h->ov.nb > 0) {
-    HIP_TRY(hipStreamCreateWithFlags(&h->ov.s2, hipStreamNonBlocking));
-    for (auto& e : h->ov.evF) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& e : h->ov.evB) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(pooled_stream(&h->ov.s2));
+    for (auto& e : h->ov.evF) HIP_TRY(pooled_event(&e, false));
+    for (auto& e : h->ov.evB) HIP_TRY(pooled_event(&e, false));
   }
   HIP_TRY(hipMemset(h->d_ps, 0, nps * 3 * sizeof(double)));
   HIP_TRY(hipMemset(h->d_yc, 0, (size_t)std::max(h->n, 1) * sizeof(double)));
@@ -1236,7 +1288,7 @@ static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, cons
   h->device = o->device; h->opt = *o;
   if (o->stream) { h->stream = (hipStream_t)o->stream; h->own_stream = false; }
   else {
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(MPSFM_EHIP, "hipStreamCreate failed"); }
+    if (pooled_stream(&h->stream) != hipSuccess) { delete h; return fail(MPSFM_EHIP, "hipStreamCreate failed"); }
     h->own_stream = true;
   }
   int rc = build(h, P, st);

@@ -236,6 +236,9 @@ struct CostArgs {
 // left in them: every consumer initialises what it reads (MPSFM_POISON=1 fills each block with 0xFF to prove it).
 void* cached_malloc(size_t bytes);
 void cached_free(void* p);
+// recycled non-blocking streams (ba_solver.hip); a released stream must be idle
+hipError_t pooled_stream(hipStream_t* s);
+void release_stream(hipStream_t s);
 
 // second stream + events for the outer-panel look-ahead of the dense factorisation (dense_chol.hip)
 struct DenseOverlap {

@@ -369,7 +369,9 @@ struct IntPool {
 
 struct StreamGuard {
   hipStream_t st = nullptr;
-  ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
+  ~StreamGuard() {
+    if (st) { (void)hipStreamSynchronize(st); release_stream(st); }  // back to the pool, idle
+  }
 };
 
 // b = 1, x0 = 0: the system of IntegrationUncertainty (column sums of the inverse)
@@ -575,7 +577,7 @@ extern "C" int mpsfm_integrate_depth_batch(int32_t n_images, const mpsfm_int_pro
   std::memset(Ss, 0, sizeof(*Ss) * (size_t)B);
   // a stream of its own: concurrent calls from different host threads overlap on the GPU
   StreamGuard sg;
-  INT_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+  INT_TRY(pooled_stream(&sg.st));
   hipStream_t st = sg.st;
   const size_t N = (size_t)P->H * P->W;
   IntBatch U;
@@ -716,7 +718,7 @@ extern "C" int mpsfm_integration_variances(const mpsfm_int_problem* P, int32_t d
   INT_TRY(hipSetDevice(device));
   std::memset(S, 0, sizeof(*S));
   StreamGuard sg;
-  INT_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+  INT_TRY(pooled_stream(&sg.st));
   hipStream_t st = sg.st;
   const int N = P->H * P->W;
   IntBatch U;
