@@ -483,7 +483,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     std::vector<int32_t> fixed_pt;
     std::vector<int64_t> nrec_of;  // records per landmark of the range
   };
-  const int mparts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (P->n_obs + P->n_dobs) / 65536));
+  const int mparts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (P->n_obs + P->n_dobs) / 32768));  // starting threads only pays above ~100 k blocks
   std::vector<MergePart> mp((size_t)mparts);
   run_parts(mparts, [&](int t, int nparts) {
     MergePart& M = mp[(size_t)t];
@@ -735,7 +735,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       double nvarpts = 0;
     };
     const int nch = (int)chunks.size();
-    const int cparts = std::max(1, std::min(host_threads(), nch / 64));
+    const int cparts = std::max(1, std::min(host_threads(), nch / 48));
     std::vector<ChunkPart> cp((size_t)cparts);
     run_parts(cparts, [&](int t, int nparts) {
       ChunkPart& C = cp[(size_t)t];
