@@ -29,7 +29,11 @@ constexpr int kThreads = 256;   // workgroup size of the sweep kernels
 constexpr int kObsMax = MPSFM_OBS_MAX;    // merged (camera, landmark) records per chunk
 constexpr int kPtsMax = MPSFM_OBS_MAX / 2;     // landmarks per chunk
 constexpr int kTileCams = MPSFM_TILE_CAMS;   // local cameras whose U blocks / g_c are accumulated in LDS
-constexpr int kLocalCamsMax = 64;  // local camera list length (beyond kTileCams: direct atomics)
+#ifndef MPSFM_LOCAL_CAMS
+#define MPSFM_LOCAL_CAMS 254
+#endif
+constexpr int kLocalCamsMax = MPSFM_LOCAL_CAMS;  // local camera list length (beyond kTileCams: direct atomics); < 255 (8-bit local index)
+static_assert(kLocalCamsMax < 255, "local camera indices are 8 bits, 0xff marks a constant camera");
 constexpr int kPairGroup = 6;   // lanes cooperating on one 6x6 block of the reduced system (one row each)
 constexpr int kItemPairs = MPSFM_ITEM_PAIRS;  // pairs per Schur work item (heavier blocks are split for balance)
 constexpr int kEntStage = MPSFM_ENT_STAGE; // pair entries of a chunk staged in LDS (larger chunks read them from HBM)

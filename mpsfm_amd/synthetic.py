@@ -110,6 +110,7 @@ def make_scene(
     perturb: bool = True,
     max_track: int = 30,
     shard: int = 0,
+    track_mean: float = 3.0,
 ) -> tuple[BAProblem, dict]:
     """Returns (problem at the perturbed initial state, ground truth dict).
 
@@ -122,7 +123,7 @@ def make_scene(
     X = rng.uniform([-3.0, -3.0, -2.0], [3.0, 3.0, 2.0], (n_pts, 3))
 
     kmax = min(max_track, n_cams)
-    k = np.clip(2 + rng.poisson(3.0, n_pts), 2, kmax).astype(np.int64)
+    k = np.clip(2 + rng.poisson(track_mean, n_pts), 2, kmax).astype(np.int64)  # track length 2 + Poisson(track_mean)
     # candidate window: cameras nearest in azimuth to the point's own azimuth
     paz = np.mod(np.arctan2(X[:, 1], X[:, 0]) + rng.normal(0, 0.2, n_pts), 2 * np.pi)
     wmax = int(min(n_cams, 2 * kmax + 8))

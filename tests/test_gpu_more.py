@@ -199,7 +199,7 @@ def test_edge_cases():
 
 
 def test_long_tracks_are_swept_by_their_own_workgroups():
-    """Tracks longer than a chunk (> 192 records or > 64 cameras): every camera sees landmarks 0..2, some
+    """Tracks longer than a chunk (> 256 records or > 254 cameras): every camera sees landmarks 0..2, some
     cameras twice (two reprojection blocks of one camera on one landmark) and with depth priors."""
     rng = np.random.default_rng(5)
     prob, truth = make_scene(260, 400, True, seed=19)
@@ -446,3 +446,23 @@ def test_outer_panel_cholesky_matches_oracle(nb, monkeypatch):
     sg, so = capi.ba_solve(pg), O.solve(po)
     assert sg["num_iterations"] == so["num_iterations"] and sg["termination"] == so["termination"]
     assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+
+
+def test_tracks_of_up_to_254_cameras_stay_on_the_chunked_path():
+    """Landmarks seen by 65..254 cameras (dense matching) are swept in chunks like short tracks (local camera list of 254
+    entries); only beyond that, or beyond 256 records, the per-landmark kernels take over.  Parity of the reduced
+    system and of the solve on tracks of ~100 cameras."""
+    prob, _ = make_scene(200, 400, True, seed=23, max_track=150, track_mean=100.0)
+    tl = np.bincount(prob.obs_pt)
+    assert tl.max() > 120 and (tl > 64).mean() > 0.9
+    ref = O.reduced_system(prob, radius=1e3)
+    with capi.BAHandle(prob.copy()) as h:
+        h.sweep_once(1e3)
+        S, rhs = h.reduced_system()
+        np.testing.assert_allclose(S, ref["S"], rtol=0, atol=1e-10 * np.abs(ref["S"]).max())
+        np.testing.assert_allclose(rhs, ref["rhs"], rtol=0, atol=1e-10 * np.abs(ref["rhs"]).max())
+    pg, po = prob.copy(), prob.copy()
+    sg, so = capi.ba_solve(pg), O.solve(po)
+    assert sg["num_iterations"] == so["num_iterations"] and sg["termination"] == so["termination"]
+    assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+    np.testing.assert_allclose(pg.cam_t, po.cam_t, atol=1e-6)
