@@ -193,12 +193,34 @@ def main():
             out["extras"] = {"integration_290x387": integration_leg(local_rank)}
         except Exception as e:  # noqa: BLE001 - never lose the headline line to the side measurement
             out["extras"] = {"integration_290x387": {"error": repr(e)}}
+        try:
+            out["extras"]["one_shot_ms"] = one_shot_leg(local_rank)
+        except Exception as e:  # noqa: BLE001
+            out["extras"]["one_shot_ms"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
     h.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def one_shot_leg(device):
+    """mpsfm_ba_solve from host buffers (table build + upload + solve + download), what one Optimizer.ba() call pays:
+    a local bundle (12 cameras / 4 k landmarks) and the C3 problem.  PCIe-inclusive, never the headline value."""
+    from mpsfm_amd import capi
+    from mpsfm_amd.synthetic import make_config, make_scene
+
+    out = {}
+    for name, base in (("local_12cam_4kpts", make_scene(12, 4000, True, seed=3)[0]), ("C3", make_config("C3")[0])):
+        ts = []
+        for _ in range(4):
+            p = base.copy()
+            t0 = time.perf_counter()
+            s = capi.ba_solve(p, capi.default_options(device=device))
+            ts.append(1e3 * (time.perf_counter() - t0))
+        out[name] = {"min": min(ts[1:]), "lm_iterations": s["num_iterations"]}
+    return out
 
 
 def integration_leg(device):
