@@ -41,6 +41,8 @@ void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const d
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
 void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov = nullptr);
+size_t dense_work_doubles(int nt);
+double* dense_pinv(double* work, int nt, const DenseOverlap* ov);
 
 thread_local std::string g_err;
 extern int g_dbg_flags;  // dense_chol.hip: bits 0-7 dense-solve ablations, bits 8-15 track-sweep ablations
@@ -946,7 +948,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   HIP_TRY(pooled_pinned((void**)&h->h_scal));
   const size_t ntiles = (size_t)(h->nt + 1) * (h->nt + 2) / 2;
   if ((rc = dev_alloc(&h->d_A, ntiles * 1024))) return rc;
-  if ((rc = dev_alloc(&h->d_dwork, (size_t)std::max(h->nt, 1) * (1024 + 32)))) return rc;
+  if ((rc = dev_alloc(&h->d_dwork, dense_work_doubles(h->nt)))) return rc;
   if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
   if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
   HIP_TRY(hipMemset(h->d_fail, 0, sizeof(int)));
@@ -955,6 +957,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if (const char* e = std::getenv("MPSFM_CHOL_NB")) h->ov.nb = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("MPSFM_CHOL_BIG")) h->ov.big = std::atoi(e) != 0;
   if (const char* e = std::getenv("MPSFM_CHOL_OVERLAP")) h->ov.overlap = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MPSFM_CHOL_INVERSE")) h->ov.no_inverse = std::atoi(e) == 0;
   if (h->nt > 64 || h->ov.nb > 0) {
     HIP_TRY(pooled_stream(&h->ov.s2));
     for (auto& e : h->ov.evF) HIP_TRY(pooled_event(&e, false));
@@ -1072,7 +1075,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
   // d_fail is zero here: cleared at creation and re-armed by k_cam_update after every read
   if (h->n > 0) {
     AssembleArgs as{h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
-                    h->opt.max_lm_diagonal, h->d_A};
+                    h->opt.max_lm_diagonal, h->d_A, dense_pinv(h->d_dwork, h->nt, &h->ov)};
     launch_assemble(as, s);
     launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov);
   }

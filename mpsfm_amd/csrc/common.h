@@ -249,6 +249,7 @@ struct DenseOverlap {
   int nb = 0;            // outer panel width in tile columns; 0: default (one panel up to 64 tile columns, else 8)
   bool big = true;       // LDS-staged 64x64 trailing update (false: per-tile workgroups, for A/B measurements)
   bool overlap = true;   // second-stream look-ahead
+  bool no_inverse = false;  // plain path: back substitution by groups instead of the inverse propagation (A/B measurements)
   hipStream_t s2 = nullptr;
   hipEvent_t evF[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t evB[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -259,6 +260,7 @@ struct AssembleArgs {
   int32_t ncv, n, nt;
   double radius, min_diag, max_diag;
   double* A;     // tiles
+  double* Pinv;  // accumulators of the inverse propagation (same tile indexing as A), zeroed here; may be NULL
 };
 
 

@@ -14,6 +14,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int kTile = 32;
 constexpr int kTileElems = kTile * kTile;
+constexpr int kPlainMaxTiles = 64;  // up to this many tile columns: one outer panel, inverse propagation instead of back substitution
 
 // one workgroup per lower tile (including the rhs tile row)
 __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
@@ -25,6 +26,9 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
   const int tj = (int)(id - (int64_t)ti * (ti + 1) / 2);
   double* T = P.A + id * kTileElems;
   const int n = P.n;
+  // the accumulators of the inverse propagation (see k_chol_step) start from zero
+  if (P.Pinv && ti < P.nt && tj < ti)
+    for (int e = threadIdx.x; e < kTileElems; e += 256) P.Pinv[id * kTileElems + e] = 0.0;
   for (int e = threadIdx.x; e < kTileElems; e += 256) {
     const int r = e >> 5, c = e & 31;
     const int C = tj * kTile + c;
@@ -391,8 +395,95 @@ extern "C" void mpsfm_debug_set(int f) { g_dbg_flags = f; }
 //   kStepBig          no factorisation: every tile (ti, tk), j < tk <= tk_max, gets columns c0..j at once
 //                     (one load and one store of the tile for a rank-32*(j-c0+1) update).
 constexpr int kStepNoOwnUpdate = 1, kStepBig = 2;
+// Inverse propagation (plain path only, Pinv != NULL).  The back substitution y = L^-T z is a chain of nt dependent
+// tile solves — ten launches of ~10 us at nt = 38.  Instead the steps also build, in the shadow of their
+// latency-bound panel factorisation, the accumulators  P(i,k) = sum_{j=k}^{i-1} L(i,j) X(j,k)  of the inverse
+// X = L^-1  (X(k,k) = L(k,k)^-1, X(i,k) = -L(i,i)^-1 P(i,k)), after which
+//   y_k = w_k - sum_{i>k} P(i,k)^T w_i,   w_i = L(i,i)^-T z_i
+// is two launches.  Launch j uses column j of L and L(j,j)^-1, both final since launch j-1:
+//   role (i, k), j < i < nt, k <= j:   P(i,k) += L(i,j) X(j,k),  X(j,k) recomputed from P(j,k) (final: it last
+//   changed in launch j-1), so no workgroup reads what another one writes in the same launch.
+// Roles are the blocks with blockIdx.y >= cols.
+#ifndef MPSFM_INV_ROWS
+#define MPSFM_INV_ROWS 2
+#endif
+constexpr int kInvRows = MPSFM_INV_ROWS;  // rows i handled by one inverse-role workgroup (X(j,k) is formed once for all of them)
+__device__ __forceinline__ void inv_role(const double* A, const double* LinvT, double* Pinv, int nt, int j, int i0, int i1, int k,
+                                         double (*s_A)[kTile + 1], double (*s_B)[kTile + 1], double* s_C, double (*s_M)[kTile + 1]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* Li = LinvT + (size_t)j * kTileElems;               // L(j,j)^-T, row-major
+  const double* Pjk = Pinv + lt_tile(j, k) * kTileElems;           // only read when k < j
+  // the first row's accumulator and A operand are requested now: their latency runs under the formation of T
+  const int m16p = lane & 15, kgp = lane >> 4;
+  v4d acc0[2];
+  double a0[8];
+  {
+    half_load_acc(Pinv + lt_tile(i0, k) * kTileElems, lane, wave, acc0);
+    const double* arow = A + lt_tile(i0, j) * kTileElems + (16 * wave + m16p) * kTile + kgp;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) a0[s] = arow[4 * s];
+  }
+  for (int e = tid; e < kTileElems; e += 128) {
+    const int r = e >> 5, c = e & 31;
+    s_B[r][c] = Li[e];
+    s_C[e] = (k < j) ? Pjk[e] : 0.0;
+  }
+  __syncthreads();
+  const int m16 = lane & 15, kg = lane >> 4;
+  // T = X(j,k): k < j: -(L(j,j)^-1 P(j,k)),  T[m][n] = -sum_q LinvT[q][m] Pjk[q][n];  k == j: L(j,j)^-1, T[m][n] = LinvT[n][m]
+  if (k < j) {
+    v4d t[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const double a = -s_B[4 * s + kg][16 * wave + m16];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) t[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, s_C[(4 * s + kg) * kTile + 16 * ni + m16], t[ni], 0, 0, 0);
+    }
+    __syncthreads();  // T overwrites L(j,j)^-T in LDS once both waves have consumed it
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_M[16 * wave + kg + 4 * r][16 * ni + m16] = t[ni][r];
+  } else {
+    double tr[kTileElems / 128];
+#pragma unroll
+    for (int u = 0; u < kTileElems / 128; ++u) { const int e = tid + 128 * u; tr[u] = s_B[e & 31][e >> 5]; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kTileElems / 128; ++u) { const int e = tid + 128 * u; s_M[e >> 5][e & 31] = tr[u]; }
+  }
+  __syncthreads();
+  // P(i,k) += L(i,j) T for the rows of this workgroup; the B operand (T) stays in registers
+  double bT[8][2];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bT[s][ni] = s_M[4 * s + kg][16 * ni + m16];
+  for (int i = i0; i < i1; ++i) {
+    double* Pik = Pinv + lt_tile(i, k) * kTileElems;
+    v4d acc[2];
+    double a[8];
+    if (i == i0) {
+      acc[0] = acc0[0]; acc[1] = acc0[1];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) a[s] = a0[s];
+    } else {
+      half_load_acc(Pik, lane, wave, acc);
+      // A operand straight from the tile in memory: lane (m, q) reads L(i,j)[16 wave + m][4 s + kg]
+      const double* arow = A + lt_tile(i, j) * kTileElems + (16 * wave + m16) * kTile + kg;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) a[s] = arow[4 * s];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bT[s][ni], acc[ni], 0, 0, 0);
+    half_store_acc(Pik, lane, wave, acc);
+  }
+}
+
 __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg, int c0, int tk_max,
-                                                   int mode) {
+                                                   int mode, double* Pinv, int cols) {
   __shared__ double s_T[kTile][kTile + 1];
   __shared__ double s_X[kTile][kTile + 1];
   __shared__ double s_Lt[kTile * kTile];
@@ -400,6 +491,15 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
   __shared__ double s_col[2][kTile];
   __shared__ int s_ready;  // columns of L published by the factorising wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (Pinv && (int)blockIdx.y >= cols) {
+    const int nrows = nt - 1 - j;  // i in (j, nt-1]
+    const int ngrp = (nrows + kInvRows - 1) / kInvRows;
+    const int role = ((int)blockIdx.y - cols) * (int)gridDim.x + (int)blockIdx.x;
+    if (j < 0 || nrows <= 0 || role >= ngrp * (j + 1) || (dbg & 8)) return;  // dbg 8: dispatch the roles, do nothing
+    const int i0 = j + 1 + (role % ngrp) * kInvRows;
+    inv_role(A, LinvT, Pinv, nt, j, i0, min(i0 + kInvRows, nt), role / ngrp, s_T, s_X, s_Lt, s_X);
+    return;
+  }
   const int tk = j + 1 + blockIdx.y;
   const int ti = j + 1 + blockIdx.x;
   if (ti < tk || tk >= nt || ti > nt || tk > tk_max) return;
@@ -414,6 +514,7 @@ __global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int
   }
   const bool own_update = (j >= 0) && !(mode & kStepNoOwnUpdate) && !(dbg & 4);
   // ---- panel column j+1 -------------------------------------------------------------------
+
   const int row = lane & 31;
   const bool diag = (ti == tk);
   if (threadIdx.x == 0) s_ready = 0;
@@ -562,6 +663,45 @@ __global__ __launch_bounds__(256) void k_backsub_group(const double* A, const do
   }
 }
 
+// ---- y = L^-T z from the inverse accumulators (two launches) --------------------------------------------
+// w_i = L(i,i)^-T z_i, z_i = row 0 of the right-hand-side tile (nt, i); y starts as w
+__global__ __launch_bounds__(64) void k_inv_w(const double* A, const double* LinvT, int nt, int n, double* wbuf, double* y) {
+  const int i = blockIdx.x, r = threadIdx.x & 31, h = threadIdx.x >> 5;
+  const double* z = A + lt_tile(nt, i) * kTileElems;
+  const double* Li = LinvT + (size_t)i * kTileElems + r * kTile;
+  double sacc = 0.0;
+#pragma unroll
+  for (int c = 16 * h; c < 16 * h + 16; ++c) sacc += Li[c] * z[c];
+  sacc += __shfl_down(sacc, 32, 64);
+  if (threadIdx.x < 32) {
+    wbuf[i * kTile + r] = sacc;
+    if (i * kTile + r < n) y[i * kTile + r] = sacc;
+  }
+}
+// y_k -= sum_{i>k, i = k+1+s (mod kInvSplit)} P(i,k)^T w_i : the long columns are cut into kInvSplit workgroups
+constexpr int kInvSplit = 4;
+__global__ __launch_bounds__(256) void k_inv_y(const double* Pinv, const double* wbuf, int nt, int n, double* y) {
+  __shared__ double s_part[8][kTile];
+  const int k = blockIdx.x, c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  if (k + 1 + (int)blockIdx.y >= nt) return;
+  double sacc = 0.0;
+  for (int i = k + 1 + (int)blockIdx.y; i < nt; i += kInvSplit) {
+    const double* Pt = Pinv + lt_tile(i, k) * kTileElems;
+    const double* w = wbuf + i * kTile;
+#pragma unroll
+    for (int r = 4 * part; r < 4 * part + 4; ++r) sacc += Pt[r * kTile + c] * w[r];
+  }
+  s_part[part][c] = sacc;
+  __syncthreads();
+  if (part == 0) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += s_part[q][c];
+    const int g = k * kTile + c;
+    if (g < n) atomicAdd(&y[g], -v);
+  }
+}
+
 // ---- host wrappers -----------------------------------------------------------------------------------
 void launch_assemble(const AssembleArgs& a, hipStream_t s) {
   const int64_t ntiles = (int64_t)(a.nt + 1) * (a.nt + 2) / 2;
@@ -576,6 +716,22 @@ static void launch_big(double* A, int nt, int j, int c0, int tk_lo, int tk_hi, h
   hipLaunchKernelGGL(k_big_update, dim3((rows + 1) / 2, (cols + 1) / 2), dim3(256), 0, s, A, nt, j, c0, tk_lo, tk_hi);
 }
 
+// layout of the work buffer: L^-T of the diagonal tiles | z | w | inverse accumulators (plain path only)
+size_t dense_work_doubles(int nt) {
+  const size_t t = (size_t)(nt > 0 ? nt : 1);
+  size_t n = t * kTileElems + 2 * t * kTile;
+  if (nt <= kPlainMaxTiles) n += (t * (t + 1) / 2) * kTileElems;
+  return n;
+}
+static int dense_panel_width(int nt, const DenseOverlap* ov) {
+  return (ov && ov->nb > 0) ? ov->nb : ((nt <= kPlainMaxTiles) ? nt : 8);
+}
+// the accumulators of the inverse propagation, or NULL when this solve does not use them (outer panels, switched off)
+double* dense_pinv(double* work, int nt, const DenseOverlap* ov) {
+  if (nt <= 0 || nt > kPlainMaxTiles || (ov && ov->no_inverse) || dense_panel_width(nt, ov) < nt) return nullptr;
+  return work + (size_t)nt * kTileElems + 2 * (size_t)nt * kTile;
+}
+
 // ov (may be NULL): a second stream and events.  With it the update of an outer panel is split: the tile
 // columns of the NEXT panel are updated on the main stream (the factorisation needs them next), the columns
 // beyond run on the second stream under the next panel's factorisation steps.
@@ -583,27 +739,33 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   if (nt <= 0) return;
   double* LinvT = work;
   double* zbuf = work + (size_t)nt * kTileElems;
+  double* wbuf = zbuf + (size_t)nt * kTile;
   // Outer panels of NB tile columns.  Inside a panel the plain right-looking steps run on the panel's
   // columns only; the tiles to the right then receive the whole panel in one launch (their load / store is
   // paid once per NB columns).  Up to 64 tile columns the matrix is one panel: exactly the plain algorithm.
-  int NB = (nt <= 64) ? nt : 8;
-  if (ov && ov->nb > 0) NB = ov->nb;
+  const int NB = dense_panel_width(nt, ov);
   const bool big_kernel = !ov || ov->big;
   const bool overlap = ov && ov->s2 && ov->overlap && big_kernel && NB < nt;
+  // inverse propagation: plain path only (one panel), unless switched off for A/B measurements
+  double* Pinv = dense_pinv(work, nt, ov);
   int npanel = 0;
   bool b_pending = false;  // an update on the second stream has been recorded in ov->evB and not yet waited for
   for (int p0 = 0; p0 < nt; p0 += NB, ++npanel) {
     const int pend = (p0 + NB - 1 < nt - 1) ? p0 + NB - 1 : nt - 1;
     // factor column p0 (its tiles already hold every earlier column); ti in [p0, nt]
     hipLaunchKernelGGL(k_chol_step, dim3(nt - p0 + 1, 1), dim3(128), 0, s, A, LinvT, nt, p0 - 1, fail, g_dbg_flags, p0 - 1, p0,
-                       kStepNoOwnUpdate);
-    for (int j = p0; j <= pend - 1; ++j)  // apply column j to columns (j, pend], factor column j+1; ti in [j+1, nt]
-      hipLaunchKernelGGL(k_chol_step, dim3(nt - j, pend - j), dim3(128), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0);
+                       kStepNoOwnUpdate, (double*)nullptr, 1);
+    for (int j = p0; j <= pend - 1; ++j) {  // apply column j to columns (j, pend], factor column j+1; ti in [j+1, nt]
+      const int rows = nt - j, cols = pend - j;
+      // inverse roles of launch j: (nt-1-j) rows x (j+1) columns, appended behind the tile grid
+      const int extra = Pinv ? (((nt - 1 - j + kInvRows - 1) / kInvRows) * (j + 1) + rows - 1) / rows : 0;
+      hipLaunchKernelGGL(k_chol_step, dim3(rows, cols + extra), dim3(128), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0, Pinv, cols);
+    }
     if (pend >= nt - 1) break;
     // columns (pend, nt-1] receive the panel p0..pend; ti in [pend+1, nt]
     if (!big_kernel) {
       hipLaunchKernelGGL(k_chol_step, dim3(nt - pend, nt - 1 - pend), dim3(128), 0, s, A, LinvT, nt, pend, fail, g_dbg_flags, p0, nt - 1,
-                         kStepBig);
+                         kStepBig, (double*)nullptr, nt - 1 - pend);
     } else if (!overlap) {
       launch_big(A, nt, pend, p0, pend + 1, nt - 1, s);
     } else {
@@ -627,6 +789,11 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   if (overlap && npanel > 0) {
     // everything queued on the second stream must be complete before the substitution (and the next assemble)
     for (int k = 0; k < 4; ++k) (void)hipStreamWaitEvent(s, ov->evB[k], 0);
+  }
+  if (Pinv) {
+    hipLaunchKernelGGL(k_inv_w, dim3(nt), dim3(64), 0, s, A, LinvT, nt, n, wbuf, y);
+    hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, Pinv, wbuf, nt, n, y);
+    return;
   }
   hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
   for (int t1 = nt; t1 > 0; t1 -= kBsG) {

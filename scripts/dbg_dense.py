@@ -6,7 +6,7 @@ prob,_=make_config("C3")
 h=capi.BAHandle(prob)
 h.sweep_once(1e4)
 L=capi.lib()
-for f in [0,1,2,3,4,7]:
+for f in [0,8,1,2,4,7]:
     L.mpsfm_debug_set(f)
     ts=[h.dense_solve_once() for _ in range(8)][3:]
     print("flags",f,"dense ms %.3f"%np.mean(ts), flush=True)
