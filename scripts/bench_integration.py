@@ -26,3 +26,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "variances":  # row f4: one solve H y = 
     for i in range(2):
         t0 = time.perf_counter(); v, sv = capi.integration_variances(*args[:7], q); t1 = time.perf_counter()
         print(f"variances: wall {1e3*(t1-t0):.1f} ms, device {sv['ms']:.2f} ms, cg {sv['cg_iterations']}, converged {sv['converged']}", flush=True)
+
+if len(sys.argv) > 1 and sys.argv[1] == "batch":  # 12 full-size maps: one by one vs one batch
+    cases = [make_maps(290, 387, seed=300 + i, n_sparse=1500) for i in range(12)]
+    def item(m):
+        nu = m["normals_uncertainty"]
+        return dict(depth_prior=m["depth_prior"], depth_uncertainty=m["depth_uncertainty"], valid=m["valid"], normals=m["normals"],
+                    normals_var=np.stack([nu[..., 0, 0], nu[..., 1, 1], nu[..., 2, 2]], -1), depth_init=m["depth_init"], K=m["K"],
+                    kps=m["kps"], depth3d=m["depth3d"], zvars3d=m["zvars3d"])
+    items = [item(m) for m in cases]
+    capi.integrate_depth_batch(items[:2])
+    t0 = time.perf_counter(); seq = [capi.integrate_depth_batch([it])[0] for it in items]; t1 = time.perf_counter()
+    bat = capi.integrate_depth_batch(items); t2 = time.perf_counter()
+    same = all(np.array_equal(a[0], b[0]) for a, b in zip(seq, bat))
+    print(f"12 maps 290x387: one by one {1e3*(t1-t0):.1f} ms, one batch {1e3*(t2-t1):.1f} ms (device {bat[0][1]['ms']:.1f} ms), identical {same}")
