@@ -272,8 +272,10 @@ int mpsfm_integrate_depth(const mpsfm_int_problem* problem, int32_t device, doub
 
 /* The same solve for a batch of images in ONE sequence of launches (what MpsfmMapper.integrate_bundle loops
  * over, reference mapper/base.py:619-631): kernels run on a (pixels, image) grid, every image keeps its own
- * IRLS / CG state and stops on its own tests, so the results are identical to n single calls while the
- * launch and synchronisation latency is paid once.  All images must share H, W and the configuration
+ * IRLS / CG state and stops on its own tests, so the results equal those of n single calls (bit for bit while
+ * the batch has fewer than 400 000 pixels in total; larger batches use two pixels per thread in the CG
+ * kernels, which regroups the partial sums: last-bit differences) while the launch and synchronisation latency
+ * is paid once.  All images must share H, W and the configuration
  * scalars (MPSFM_EINVAL otherwise); summaries[i].ms is the device time of the whole batch. */
 int mpsfm_integrate_depth_batch(int32_t n_images, const mpsfm_int_problem* problems /* [n] */, int32_t device,
                                 double* const* depth_out /* [n] pointers to H*W */, mpsfm_int_summary* summaries /* [n] */);

@@ -26,10 +26,9 @@ static int ifail(int code, const std::string& m) { g_err = m; return code; }
   } while (0)
 
 constexpr int kIT = 256;  // threads per workgroup
-#ifndef MPSFM_INT_PIX
-#define MPSFM_INT_PIX 1
-#endif
-constexpr int kPix = MPSFM_INT_PIX;  // pixels per thread in the CG kernels (4 measured 20 % slower than 1: the kernels are latency-bound)
+// Pixels per thread in the CG kernels, chosen per solve: one image (112 k pixels) is latency-bound and fastest
+// with 1; a batch of full-size maps is bandwidth-bound and 23 % faster with 2 (more bytes in flight per lane).
+constexpr size_t kPixSwitch = 400000;  // total pixels of the batch from which 2 pixels per thread are used
 
 // A batch of B images of one size: every per-pixel array is [B][N] (w4: [B][4][N]); part is [B][G][8],
 // state [B][8].  Kernels are launched on a (G, B) grid; blockIdx.y picks the image.
@@ -243,13 +242,14 @@ __device__ __forceinline__ double stencil_apply(const IntDev& D, const double* x
 }
 
 // r = b - A z, zz = M r; partials: 0 (r,zz), 1 (r,r), 2 (b,b)
+template <int PIX>
 __global__ __launch_bounds__(kIT) void k_cg_init(IntDev Dall) {
   if (!Dall.act[blockIdx.y]) return;
   const IntDev D = int_image(Dall, blockIdx.y);
   double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-  for (int u = 0; u < kPix; ++u) {
-    const int p = (blockIdx.x * kPix + u) * kIT + threadIdx.x;
+  for (int u = 0; u < PIX; ++u) {
+    const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
     if (p < D.N) {
       const int row = p / D.W, col = p - row * D.W;
       const double r = D.b[p] - stencil_apply(D, D.z, p, row, col);
@@ -264,6 +264,7 @@ __global__ __launch_bounds__(kIT) void k_cg_init(IntDev Dall) {
 // state: [0] rho_prev, [1] atol^2, [2] done, [3] iterations, [4] rho_cur (for the update kernel)
 // Direction + matvec: p_new = zz + beta p_old, q = A p_new; partial 0: (p_new, q).
 // Stops (and marks done) when |r| < atol, like scipy.sparse.linalg.cg's loop head.
+template <int PIX>
 __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it, int first, double rtol) {
   if (!Dall.act[blockIdx.y]) return;
   const IntDev D = int_image(Dall, blockIdx.y);
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it
   double* pnew = (it & 1) ? D.p0 : D.p1;
   double v[1] = {0.0};
 #pragma unroll
-  for (int u = 0; u < kPix; ++u) {
-    const int p = (blockIdx.x * kPix + u) * kIT + threadIdx.x;
+  for (int u = 0; u < PIX; ++u) {
+    const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
     if (!done && p < D.N) {
       const int W = D.W, H = D.H;
       const int row = p / W, col = p - row * W;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it
 }
 
 // x += alpha p, r -= alpha q, zz = M r; partials 0 (r,zz), 1 (r,r)
+template <int PIX>
 __global__ __launch_bounds__(kIT) void k_cg_update(IntDev Dall, int nblocks, int it) {
   if (!Dall.act[blockIdx.y]) return;
   const IntDev D = int_image(Dall, blockIdx.y);
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(kIT) void k_cg_update(IntDev Dall, int nblocks, int
   const double* pnew = (it & 1) ? D.p0 : D.p1;
   double v[2] = {0.0, 0.0};
 #pragma unroll
-  for (int u = 0; u < kPix; ++u) {
-    const int p = (blockIdx.x * kPix + u) * kIT + threadIdx.x;
+  for (int u = 0; u < PIX; ++u) {
+    const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
     if (p < D.N) {
       double r = D.r[p];
       if (!done) {
@@ -530,17 +532,24 @@ static void int_launch_prepare(const mpsfm_int_problem* P0, IntBatch& U, hipStre
 // 16 iterations.  its[b] / conv[b] are written for the active images.
 static int int_run_cg(IntBatch& U, hipStream_t st, double rtol, int max_iter, int* its, bool* conv) {
   IntDev& D = U.D;
-  const int Gc = (int)((U.N + (size_t)kIT * kPix - 1) / ((size_t)kIT * kPix));  // workgroups (= partial rows) of the CG kernels
+  const int pix = ((size_t)U.B * U.N >= kPixSwitch) ? 2 : 1;
+  const int Gc = (int)((U.N + (size_t)kIT * pix - 1) / ((size_t)kIT * pix));  // workgroups (= partial rows) of the CG kernels
   const dim3 grid(Gc, U.B);
   INT_TRY(hipMemsetAsync(D.state, 0, sizeof(double) * 8 * U.B, st));
-  hipLaunchKernelGGL(k_cg_init, grid, dim3(kIT), 0, st, D);
+  if (pix == 2) hipLaunchKernelGGL(k_cg_init<2>, grid, dim3(kIT), 0, st, D);
+  else hipLaunchKernelGGL(k_cg_init<1>, grid, dim3(kIT), 0, st, D);
   int k = 0;
   bool done = false;
   while (!done && k < max_iter) {
     const int batch = std::min(16, max_iter - k);
     for (int j = 0; j < batch; ++j, ++k) {
-      hipLaunchKernelGGL(k_cg_dir, grid, dim3(kIT), 0, st, D, Gc, k, k == 0 ? 1 : 0, rtol);
-      hipLaunchKernelGGL(k_cg_update, grid, dim3(kIT), 0, st, D, Gc, k);
+      if (pix == 2) {
+        hipLaunchKernelGGL(k_cg_dir<2>, grid, dim3(kIT), 0, st, D, Gc, k, k == 0 ? 1 : 0, rtol);
+        hipLaunchKernelGGL(k_cg_update<2>, grid, dim3(kIT), 0, st, D, Gc, k);
+      } else {
+        hipLaunchKernelGGL(k_cg_dir<1>, grid, dim3(kIT), 0, st, D, Gc, k, k == 0 ? 1 : 0, rtol);
+        hipLaunchKernelGGL(k_cg_update<1>, grid, dim3(kIT), 0, st, D, Gc, k);
+      }
     }
     INT_TRY(hipMemcpyAsync(U.hstate, D.state, sizeof(double) * 8 * U.B, hipMemcpyDeviceToHost, st)); INT_TRY(hipStreamSynchronize(st));
     done = true;
