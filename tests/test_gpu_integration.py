@@ -373,3 +373,17 @@ def test_integrate_bundle_batched_on_a_scene():
         assert x.last_integration_summary["cg_iters"] == y.last_integration_summary["cg_iters"]
     assert integrate_bundle(b) == [False] * len(b)  # nothing changed since: every frame is skipped
     assert integrate_bundle(b, batched=False) == [False] * len(b)
+
+
+@pytest.mark.gpu
+def test_large_batches_use_the_two_pixel_kernels_and_still_match():
+    """From 400 000 pixels in a call the CG kernels handle two pixels per thread (bandwidth-bound regime): partial sums are
+    regrouped, so results match the single calls to rounding amplified by the 1e-3 CG tolerance, not bit for bit."""
+    cases = [make_maps(290, 387, seed=400 + i, n_sparse=800) for i in range(4)]
+    singles = [_hip(m) for m in cases]
+    batch = capi.integrate_depth_batch([_item(m) for m in cases])
+    for (d1, s1, *_), (d2, s2, *_) in zip(singles, batch):
+        assert s1["changed"] and s2["changed"] and s1["irls_iterations"] == s2["irls_iterations"]
+        assert all(abs(a - b) <= 1 for a, b in zip(s1["cg_iters"], s2["cg_iters"]))
+        np.testing.assert_allclose(s1["energies"], s2["energies"], rtol=1e-7)
+        np.testing.assert_allclose(d1, d2, rtol=1e-6)
