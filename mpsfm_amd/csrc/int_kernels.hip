@@ -268,6 +268,36 @@ template <int PIX>
 __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it, int first, double rtol) {
   if (!Dall.act[blockIdx.y]) return;
   const IntDev D = int_image(Dall, blockIdx.y);
+  const double* pold = (it & 1) ? D.p1 : D.p0;
+  double* pnew = (it & 1) ? D.p0 : D.p1;
+  const int W = D.W, H = D.H;
+  // Operands first: their loads do not depend on the scalars of the prologue below, whose chain (read the
+  // partials of every workgroup, reduce, barrier) is about half of this kernel's duration.  Absent neighbours
+  // get a zero coupling, so the arithmetic needs no further bounds tests.
+  // (Only with one pixel per thread, the latency-bound regime: with two, the bandwidth-bound one, the extra live
+  // registers cost more occupancy than the overlap gains — 48.6 vs 60.3 ms on 12 full-size maps.)
+  constexpr bool kPreload = (PIX == 1);
+  double zc[PIX][5], pc_[PIX][5], dd[PIX], wl[PIX], wr[PIX], wu[PIX], wd[PIX];
+  auto load_operands = [&]() {
+#pragma unroll
+  for (int u = 0; u < PIX; ++u) {
+    const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
+    const bool in = p < D.N;
+    const int row = in ? p / W : 0, col = in ? p - row * W : 0;
+    const bool hl = in && col >= 1, hr = in && col <= W - 2, hu = in && row >= 1, hd = in && row <= H - 2;
+    const int nb[5] = {p, p - 1, p + 1, p - W, p + W};
+    const bool ok[5] = {in, hl, hr, hu, hd};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      zc[u][k] = ok[k] ? D.zz[nb[k]] : 0.0;
+      pc_[u][k] = (ok[k] && !first) ? pold[nb[k]] : 0.0;
+    }
+    dd[u] = in ? D.d[p] : 0.0;
+    wl[u] = hl ? D.cr[p - 1] : 0.0; wr[u] = hr ? D.cr[p] : 0.0;
+    wu[u] = hu ? D.cd[p - W] : 0.0; wd[u] = hd ? D.cd[p] : 0.0;
+  }
+  };
+  if (kPreload) load_operands();
   double sums[3];
   sum_partials<3>(D.part, nblocks, 0, sums);  // (r,zz), (r,r), (b,b)
   const double rho = sums[0], rr = sums[1];
@@ -277,25 +307,44 @@ __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // publish for the update kernel and the next direction kernel
     D.state[5] = atol2; D.state[6] = done ? 1.0 : 0.0; D.state[4] = rho;
   }
-  const double* pold = (it & 1) ? D.p1 : D.p0;
-  double* pnew = (it & 1) ? D.p0 : D.p1;
   double v[1] = {0.0};
+  if constexpr (!kPreload) {
+    // streaming form: operands are consumed as they arrive, pixel by pixel (fewer live registers)
+#pragma unroll
+    for (int u = 0; u < PIX; ++u) {
+      const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
+      if (!done && p < D.N) {
+        const int row = p / W, col = p - row * W;
+        auto pnv = [&](int q) { return first ? D.zz[q] : D.zz[q] + beta * pold[q]; };
+        const double pc = pnv(p);
+        double q = D.d[p] * pc;
+        if (col >= 1) q += D.cr[p - 1] * pnv(p - 1);
+        if (col <= W - 2) q += D.cr[p] * pnv(p + 1);
+        if (row >= 1) q += D.cd[p - W] * pnv(p - W);
+        if (row <= H - 2) q += D.cd[p] * pnv(p + W);
+        pnew[p] = pc; D.q[p] = q;
+        v[0] += pc * q;
+      }
+    }
+  } else {
 #pragma unroll
   for (int u = 0; u < PIX; ++u) {
     const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
     if (!done && p < D.N) {
-      const int W = D.W, H = D.H;
-      const int row = p / W, col = p - row * W;
-      auto pn = [&](int q) { return first ? D.zz[q] : D.zz[q] + beta * pold[q]; };
-      const double pc = pn(p);
-      double q = D.d[p] * pc;
-      if (col >= 1) q += D.cr[p - 1] * pn(p - 1);
-      if (col <= W - 2) q += D.cr[p] * pn(p + 1);
-      if (row >= 1) q += D.cd[p - W] * pn(p - W);
-      if (row <= H - 2) q += D.cd[p] * pn(p + W);
+      double pn[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pn[k] = first ? zc[u][k] : zc[u][k] + beta * pc_[u][k];
+      const double pc = pn[0];
+      // same order of additions as the reference stencil: diagonal, left, right, up, down
+      double q = dd[u] * pc;
+      q += wl[u] * pn[1];
+      q += wr[u] * pn[2];
+      q += wu[u] * pn[3];
+      q += wd[u] * pn[4];
       pnew[p] = pc; D.q[p] = q;
       v[0] += pc * q;
     }
+  }
   }
   // the partial slots 0..2 are still being read by slower workgroups of this launch: use slots 4..
   __syncthreads();
@@ -313,6 +362,20 @@ template <int PIX>
 __global__ __launch_bounds__(kIT) void k_cg_update(IntDev Dall, int nblocks, int it) {
   if (!Dall.act[blockIdx.y]) return;
   const IntDev D = int_image(Dall, blockIdx.y);
+  const double* pnew = (it & 1) ? D.p0 : D.p1;
+  // operands before the prologue (see k_cg_dir)
+  constexpr bool kPreload = (PIX == 1);
+  double lp[PIX], lq[PIX], lr[PIX], lz[PIX], lm[PIX], lzz[PIX];
+  auto load_operands = [&]() {
+#pragma unroll
+    for (int u = 0; u < PIX; ++u) {
+      const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
+      const bool in = p < D.N;
+      lp[u] = in ? pnew[p] : 0.0; lq[u] = in ? D.q[p] : 0.0; lr[u] = in ? D.r[p] : 0.0;
+      lz[u] = in ? D.z[p] : 0.0; lm[u] = in ? D.minv[p] : 0.0; lzz[u] = in ? D.zz[p] : 0.0;
+    }
+  };
+  if (kPreload) load_operands();
   double pq[1];
   sum_partials<1>(D.part, nblocks, 4, pq);
   const bool done = D.state[6] != 0.0;
@@ -322,21 +385,38 @@ __global__ __launch_bounds__(kIT) void k_cg_update(IntDev Dall, int nblocks, int
     D.state[2] = D.state[6];
     if (!done) { D.state[0] = D.state[4]; D.state[3] += 1.0; }
   }
-  const double* pnew = (it & 1) ? D.p0 : D.p1;
   double v[2] = {0.0, 0.0};
+  if constexpr (!kPreload) {
+#pragma unroll
+    for (int u = 0; u < PIX; ++u) {
+      const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
+      if (p < D.N) {
+        double r = D.r[p];
+        if (!done) {
+          D.z[p] += alpha * pnew[p];
+          r -= alpha * D.q[p];
+          D.r[p] = r;
+          D.zz[p] = D.minv[p] * r;
+        }
+        v[0] += r * D.zz[p]; v[1] += r * r;
+      }
+    }
+  } else {
 #pragma unroll
   for (int u = 0; u < PIX; ++u) {
     const int p = (blockIdx.x * PIX + u) * kIT + threadIdx.x;
     if (p < D.N) {
-      double r = D.r[p];
+      double r = lr[u], zz = lzz[u];
       if (!done) {
-        D.z[p] += alpha * pnew[p];
-        r -= alpha * D.q[p];
+        D.z[p] = lz[u] + alpha * lp[u];
+        r -= alpha * lq[u];
+        zz = lm[u] * r;
         D.r[p] = r;
-        D.zz[p] = D.minv[p] * r;
+        D.zz[p] = zz;
       }
-      v[0] += r * D.zz[p]; v[1] += r * r;
+      v[0] += r * zz; v[1] += r * r;
     }
+  }
   }
   block_partials<2>(v, D.part);
 }
