@@ -268,6 +268,11 @@ template <int PIX>
 __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it, int first, double rtol) {
   if (!Dall.act[blockIdx.y]) return;
   const IntDev D = int_image(Dall, blockIdx.y);
+  // This image's solve has met its test in an earlier iteration (the host only looks every 16): nothing left to do,
+  // and in a batch a finished image stops taking bandwidth from the others.  The flag is requested now and tested
+  // after the operand loads have been issued (one-pixel variant), so the test adds no memory round trip of its own.
+  const double finished = first ? 0.0 : D.state[2];
+  if (PIX != 1 && finished != 0.0) return;
   const double* pold = (it & 1) ? D.p1 : D.p0;
   double* pnew = (it & 1) ? D.p0 : D.p1;
   const int W = D.W, H = D.H;
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(kIT) void k_cg_dir(IntDev Dall, int nblocks, int it
   }
   };
   if (kPreload) load_operands();
+  if (PIX == 1 && finished != 0.0) return;
   double sums[3];
   sum_partials<3>(D.part, nblocks, 0, sums);  // (r,zz), (r,r), (b,b)
   const double rho = sums[0], rr = sums[1];
@@ -362,6 +368,8 @@ template <int PIX>
 __global__ __launch_bounds__(kIT) void k_cg_update(IntDev Dall, int nblocks, int it) {
   if (!Dall.act[blockIdx.y]) return;
   const IntDev D = int_image(Dall, blockIdx.y);
+  const double finished = D.state[2];  // set in an earlier iteration by this kernel's block 0 (below); tested after the loads
+  if (PIX != 1 && finished != 0.0) return;
   const double* pnew = (it & 1) ? D.p0 : D.p1;
   // operands before the prologue (see k_cg_dir)
   constexpr bool kPreload = (PIX == 1);
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(kIT) void k_cg_update(IntDev Dall, int nblocks, int
     }
   };
   if (kPreload) load_operands();
+  if (PIX == 1 && finished != 0.0) return;
   double pq[1];
   sum_partials<1>(D.part, nblocks, 4, pq);
   const bool done = D.state[6] != 0.0;
