@@ -466,3 +466,25 @@ def test_tracks_of_up_to_254_cameras_stay_on_the_chunked_path():
     assert sg["num_iterations"] == so["num_iterations"] and sg["termination"] == so["termination"]
     assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
     np.testing.assert_allclose(pg.cam_t, po.cam_t, atol=1e-6)
+
+
+def test_inverse_propagation_equals_grouped_back_substitution(monkeypatch):
+    """y = L^-T z through the accumulators of L^-1 built during the factorisation (default up to 64 tile columns) against
+    the grouped back substitution (MPSFM_CHOL_INVERSE=0) and numpy on the same reduced system, at two dampings."""
+    prob, _ = make_scene(60, 6000, True, seed=71)
+    ys = {}
+    for inverse in ("1", "0"):
+        monkeypatch.setenv("MPSFM_CHOL_INVERSE", inverse)
+        with capi.BAHandle(prob.copy()) as h:
+            for radius in (1e4, 1e-1):
+                h.sweep_once(radius)
+                h.dense_solve_once()
+                y = h.dense_solution()
+                S, rhs = h.reduced_system()
+                if inverse == "1":
+                    y_np = np.linalg.solve(S, rhs)
+                    np.testing.assert_allclose(y, y_np, rtol=0, atol=1e-9 * np.abs(y_np).max())
+                ys[(inverse, radius)] = y
+    for radius in (1e4, 1e-1):
+        a, b = ys[("1", radius)], ys[("0", radius)]
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-10 * np.abs(b).max())
