@@ -15,7 +15,7 @@ import numpy as np
 
 from ...baseclass import BaseClass
 from ...problem import Tracks
-from ...utils_geometry import has_point_positive_depth
+from ...utils.geometry import has_point_positive_depth
 
 
 def tracks_from_scene(scene, point3D_ids) -> tuple[Tracks, list]:

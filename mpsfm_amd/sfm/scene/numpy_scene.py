@@ -23,6 +23,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from ...synthetic import R_from_quat, quat_from_R
+from ...utils.geometry import project3D_colmap
 from .priorutils import PriorUtils
 
 INVALID_POINT3D = 18446744073709551615  # pycolmap's kInvalidPoint3DId (reference triangulator.py:109)
@@ -171,7 +172,8 @@ class NumpyImage:
 
 
 class PointCovs:
-    """reference mpsfm/sfm/scene/pointcov.py:4-20"""
+    """reference mpsfm/sfm/scene/pointcov.py:4-20 (pinned by tests/golden/reference_geometry_pointcov.npz).
+    The reference evaluates (R^T C R)[2, 2] with R = cam_from_world rotation — kept as it is."""
 
     def __init__(self):
         self.data = {}
@@ -181,7 +183,7 @@ class PointCovs:
             p3d_ids = [p.point3D_id for p in image.points2D if p.has_point3D()]
         R = image.cam_from_world.rotation.matrix()
         data = np.array([self.data[p] for p in p3d_ids])
-        return p3d_ids, np.einsum("ij,njk,lk->nil", R, data, R)[:, 2, 2]
+        return p3d_ids, np.einsum("ji,njk,kl->nil", R, data, R)[:, 2, 2]
 
 
 class _Rec:
@@ -247,12 +249,29 @@ class NumpyReconstruction:
             pts3dids = image.point3D_ids(pts2dids)
             if len(pts3dids) == 0:
                 return None, None, None, None, False
-        X = self.point3D_coordinates(pts3dids)
-        Xc = image.cam_from_world * X
-        depth = Xc[:, 2].copy()
-        K = self.rec.cameras[image.camera_id].calibration_matrix()
-        kps = (Xc / depth[:, None]) @ K.T
-        return pts2dids, pts3dids, kps[:, :2], depth, True
+        kps, depth = project3D_colmap(image, self.rec.cameras[image.camera_id], self.point3D_coordinates(pts3dids))
+        return pts2dids, pts3dids, kps, depth, True
+
+    def lifted_pointcovs_cam(self, dd, camera, keypoints, var_d, sigma_q=1):
+        """Camera-frame covariance of points lifted from depth dd at `keypoints`: depth variance along the
+        viewing ray plus pixel noise sigma_q in the image plane (reference points3D_utils.py:27-48)."""
+        ff_inv = 1.0 / np.array([camera.focal_length_x, camera.focal_length_y])
+        cc = np.array([camera.principal_point_x, camera.principal_point_y])
+        ray = np.concatenate([(keypoints - cc) * ff_inv, np.ones((keypoints.shape[0], 1))], axis=1)
+        cov = var_d[:, None, None] * ray[:, :, None] * ray[:, None, :]
+        px = np.clip(dd[:, None] * ff_inv[None, :], -1e6, 1e6) ** 2 * sigma_q**2
+        cov[:, 0, 0] += px[:, 0]
+        cov[:, 1, 1] += px[:, 1]
+        return cov
+
+    def rotate_covs(self, Covs, R):
+        return R[None] @ Covs @ R.T[None]
+
+    def rotate_covs_to_world(self, Covs, imid):
+        return self.rotate_covs(Covs, self.images[imid].cam_from_world.rotation.matrix())
+
+    def rotate_covs_to_cam(self, Covs_world, imid):
+        return self.rotate_covs(Covs_world, self.images[imid].cam_from_world.rotation.matrix().T)
 
     def find_points3D_with_small_triangulation_angle(self, min_angle, point3D_ids):
         return np.array(self.obs.find_small_angle_points_mask(float(min_angle), point3D_ids))

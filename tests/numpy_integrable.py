@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .integration import Integration
+from mpsfm_amd.sfm.scene.integration import Integration
 
 
 class NumpyNormals:

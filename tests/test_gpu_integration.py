@@ -110,7 +110,7 @@ def test_integration_mixin_on_a_scene_matches_oracle():
     covariances, robust-triangle filter — gathered by the mixin, solved in HIP, compared with the oracle fed
     with the same gathered inputs."""
     from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
-    from mpsfm_amd.sfm.scene.numpy_integrable import NumpyIntegrableImage, NumpyNormals
+    from numpy_integrable import NumpyIntegrableImage, NumpyNormals
     from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
     from mpsfm_amd.synthetic import make_scene
 
@@ -228,7 +228,7 @@ def test_int_covs_at_kps_through_the_mixin():
     mapper/base.py:621-627), full-resolution and downscaled, against the oracle fed with the same inputs."""
     from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
     from mpsfm_amd.sfm.scene.integration import resize_linear
-    from mpsfm_amd.sfm.scene.numpy_integrable import NumpyIntegrableImage, NumpyNormals
+    from numpy_integrable import NumpyIntegrableImage, NumpyNormals
     from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
     from mpsfm_amd.synthetic import make_scene
 
@@ -343,7 +343,7 @@ def test_integrate_bundle_batched_on_a_scene():
     integrating the images one after the other."""
     from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
     from mpsfm_amd.sfm.scene.integration import integrate_bundle
-    from mpsfm_amd.sfm.scene.numpy_integrable import NumpyIntegrableImage, NumpyNormals
+    from numpy_integrable import NumpyIntegrableImage, NumpyNormals
     from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
     from mpsfm_amd.synthetic import make_scene
 
