@@ -199,11 +199,20 @@ struct Stager {
   bool busy[2] = {false, false};
   int next = 0;
   int init() {
-    if (buf) return 0;
-    if (hipHostMalloc((void**)&buf, 2 * kHalf, hipHostMallocDefault) != hipSuccess) { buf = nullptr; return fail(MPSFM_ENOMEM, "hipHostMalloc (staging) failed"); }
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    if (buf) return 0;  // set last: a partly created stager is torn down again and the next call retries
+    char* b = nullptr;
+    if (hipHostMalloc((void**)&b, 2 * kHalf, hipHostMallocDefault) != hipSuccess) return fail(MPSFM_ENOMEM, "hipHostMalloc (staging) failed");
+    const bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+      if (st) (void)hipStreamDestroy(st);
+      st = nullptr;
+      (void)hipHostFree(b);
+      return fail(MPSFM_EHIP, "creating the staging stream / events failed");
+    }
+    buf = b;
     return 0;
   }
   // blocking from the caller's point of view only at drain()
@@ -351,6 +360,11 @@ namespace mpsfm {
 static void free_handle(mpsfm_ba_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  // Error returns of the solve (a failing all-reduce hook, a HIP error) and reset_state + destroy leave copies and
+  // kernels in flight: both streams must be idle before the blocks go back to the process-wide cache, where a
+  // handle on another stream or host thread may receive them at once.
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->ov.s2) (void)hipStreamSynchronize(h->ov.s2);
   void* ptrs[] = {h->d_q, h->d_t, h->d_q2, h->d_t2, h->d_q0, h->d_t0, h->d_pts, h->d_pts2, h->d_pts0, h->d_intr, h->d_cmask,
                   h->d_cs, h->d_camtab, h->d_camtab2, h->d_intr_idx, h->d_cam_slot, h->d_ps, h->d_diagV, h->d_chunks,
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
@@ -1271,6 +1285,7 @@ static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, cons
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MPSFM_ENODEVICE, "no HIP device visible: libmpsfm_hip has no CPU fallback");
   if (o->device < 0 || o->device >= ndev) return fail(MPSFM_EINVAL, "device ordinal out of range");
+  if (o->device >= kMaxDevices) return fail(MPSFM_EUNSUPPORTED, "device ordinals beyond 15 are not supported (per-device pools)");
   {
     // the architecture of a device does not change: query it once per process and device
     static std::mutex mu;

@@ -37,6 +37,8 @@ static_assert(kLocalCamsMax < 255, "local camera indices are 8 bits, 0xff marks 
 constexpr int kPairGroup = 6;   // lanes cooperating on one 6x6 block of the reduced system (one row each)
 constexpr int kItemPairs = MPSFM_ITEM_PAIRS;  // pairs per Schur work item (heavier blocks are split for balance)
 constexpr int kEntStage = MPSFM_ENT_STAGE; // pair entries of a chunk staged in LDS (larger chunks read them from HBM)
+static_assert(kObsMax <= 256 && kPtsMax <= 128, "chunk-relative record / landmark indices are packed into 8 bits (rec_meta, pair entries)");
+constexpr int kMaxDevices = 16;  // per-device pools (allocator cache, streams, staging buffers) are arrays of this length
 constexpr int kWStride = 18;    // row stride (doubles) of the per-record W block in LDS: 144 B, keeps rows 16-B aligned for ds_read_b128
 constexpr int kCamRec = 24;     // doubles per camera table record
 

@@ -499,6 +499,7 @@ static int int_check(const mpsfm_int_problem* P, int32_t device) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ifail(MPSFM_ENODEVICE, "no HIP device visible: libmpsfm_hip has no CPU fallback");
   if (device < 0 || device >= ndev) return ifail(MPSFM_EINVAL, "device ordinal out of range");
+  if (device >= kMaxDevices) return ifail(MPSFM_EUNSUPPORTED, "device ordinals beyond 15 are not supported (per-device pools)");
   for (int i = 0; i < P->n_sparse; ++i)
     if (P->sparse_x[i] < 0 || P->sparse_x[i] >= P->W || P->sparse_y[i] < 0 || P->sparse_y[i] >= P->H)
       return ifail(MPSFM_EINVAL, "sparse pixel outside the map");
@@ -674,11 +675,13 @@ extern "C" int mpsfm_integrate_depth_batch(int32_t n_images, const mpsfm_int_pro
   INT_TRY(hipSetDevice(device));
   std::memset(Ss, 0, sizeof(*Ss) * (size_t)B);
   // a stream of its own: concurrent calls from different host threads overlap on the GPU
+  // U before the guard: destructors run in reverse order, so every early `return rc` first waits for the stream
+  // (the guard) and only then hands U's device blocks back to the caching allocator
+  IntBatch U;
   StreamGuard sg;
   INT_TRY(pooled_stream(&sg.st));
   hipStream_t st = sg.st;
   const size_t N = (size_t)P->H * P->W;
-  IntBatch U;
   if (int rc = int_setup(Ps, B, true, P->scale_filter != 0, st, U)) return rc;
   IntDev& D = U.D;
   const dim3 grid(U.G, B);
@@ -815,11 +818,11 @@ extern "C" int mpsfm_integration_variances(const mpsfm_int_problem* P, int32_t d
     if (qx[i] < 0 || qx[i] >= P->W || qy[i] < 0 || qy[i] >= P->H) return ifail(MPSFM_EINVAL, "query pixel outside the map");
   INT_TRY(hipSetDevice(device));
   std::memset(S, 0, sizeof(*S));
+  IntBatch U;  // before the guard, see mpsfm_integrate_depth_batch
   StreamGuard sg;
   INT_TRY(pooled_stream(&sg.st));
   hipStream_t st = sg.st;
   const int N = P->H * P->W;
-  IntBatch U;
   if (int rc = int_setup(P, 1, use_sparse != 0, false, st, U)) return rc;  // calculate_hessian applies no scale filter (:542)
   IntDev& D = U.D;
   const dim3 grid(U.G, 1);

@@ -24,7 +24,12 @@ static int tfail(int code, const std::string& m) { g_err = m; return code; }
 
 struct DevBuf {
   std::vector<void*> ptrs;
-  ~DevBuf() { for (void* p : ptrs) cached_free(p); }
+  // the kernels of this file run on the null stream: it must be idle before the blocks go back to the caching
+  // allocator (an early return on a failed call would otherwise free memory that is still in use)
+  ~DevBuf() {
+    if (!ptrs.empty()) (void)hipStreamSynchronize(nullptr);
+    for (void* p : ptrs) cached_free(p);
+  }
   template <typename T>
   T* up(const T* host, size_t n, bool copy = true) {
     void* p = nullptr;
@@ -40,6 +45,7 @@ static int check_device(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return tfail(MPSFM_ENODEVICE, "no HIP device visible: libmpsfm_hip has no CPU fallback");
   if (device < 0 || device >= n) return tfail(MPSFM_EINVAL, "device ordinal out of range");
+  if (device >= kMaxDevices) return tfail(MPSFM_EUNSUPPORTED, "device ordinals beyond 15 are not supported (per-device pools)");
   TRI_TRY(hipSetDevice(device));
   return 0;
 }
@@ -227,10 +233,13 @@ static int check_tracks(const mpsfm_tracks* T) {
   if (!T || T->n_tracks < 0 || T->n_cams < 0) return tfail(MPSFM_EINVAL, "tracks is NULL or has negative sizes");
   if (T->n_tracks > 0 && !T->track_start) return tfail(MPSFM_EINVAL, "track_start is NULL");
   if (T->n_tracks == 0) return 0;
+  if (T->n_intr < 0 || (T->n_cams > 0 && (!T->cam_quat_xyzw || !T->cam_t || !T->cam_intr || !T->cam_intr_idx)))
+    return tfail(MPSFM_EINVAL, "camera arrays are NULL");
   if (T->track_start[0] != 0) return tfail(MPSFM_EINVAL, "track_start[0] must be 0");
   for (int i = 0; i < T->n_tracks; ++i)
     if (T->track_start[i + 1] < T->track_start[i]) return tfail(MPSFM_EINVAL, "track_start must be non-decreasing");
   const int64_t ne = T->track_start[T->n_tracks];
+  if (ne > 0 && (!T->el_cam || !T->el_xy)) return tfail(MPSFM_EINVAL, "track element arrays are NULL");
   for (int64_t e = 0; e < ne; ++e)
     if (T->el_cam[e] < 0 || T->el_cam[e] >= T->n_cams) return tfail(MPSFM_EINVAL, "el_cam out of range");
   for (int i = 0; i < T->n_cams; ++i)
@@ -260,7 +269,10 @@ extern "C" {
 
 int mpsfm_point_covs(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, int32_t device, double* covs) {
   if (!P || !st || !covs) return tfail(MPSFM_EINVAL, "NULL argument");
-  if (P->n_pts < 0 || P->n_cams < 0 || P->n_obs < 0) return tfail(MPSFM_EINVAL, "negative size");
+  if (P->n_pts < 0 || P->n_cams < 0 || P->n_obs < 0 || P->n_intr < 0) return tfail(MPSFM_EINVAL, "negative size");
+  if (P->n_obs > 0 && (!P->obs_cam || !P->obs_pt || !P->obs_xy)) return tfail(MPSFM_EINVAL, "observation arrays are NULL");
+  if (P->n_cams > 0 && (!P->cam_intr_idx || !P->cam_intr || !st->cam_quat_xyzw || !st->cam_t)) return tfail(MPSFM_EINVAL, "camera arrays are NULL");
+  if (P->n_pts > 0 && !st->pts) return tfail(MPSFM_EINVAL, "pts is NULL");
   for (int64_t i = 0; i < P->n_obs; ++i)
     if (P->obs_cam[i] < 0 || P->obs_cam[i] >= P->n_cams || P->obs_pt[i] < 0 || P->obs_pt[i] >= P->n_pts)
       return tfail(MPSFM_EINVAL, "observation index out of range");

@@ -25,6 +25,21 @@ from ..scene.priorutils import fit_robust_gaussian_mad
 _COLMAP_LOSS = {"TRIVIAL": LOSS_TRIVIAL, "SOFT_L1": LOSS_SOFT_L1, "CAUCHY": LOSS_CAUCHY}
 
 
+def pinhole_params(camera) -> np.ndarray:
+    """[fx, fy, cx, cy] of a camera.  The kernels implement COLMAP's PINHOLE projection only (the reference's own
+    loader creates nothing else, data_proc/simple.py:53-60); SIMPLE_PINHOLE is widened to (f, f, cx, cy), any other
+    model is refused instead of being optimised with a wrong projection."""
+    model = getattr(camera, "model", None)
+    name = getattr(model, "name", model)
+    name = "PINHOLE" if name is None else str(name).split(".")[-1]
+    params = np.asarray(camera.params, np.float64)
+    if name == "PINHOLE":
+        return params[:4]
+    if name == "SIMPLE_PINHOLE":
+        return np.array([params[0], params[0], params[1], params[2]])
+    raise NotImplementedError(f"camera model {name}: libmpsfm_hip implements the PINHOLE reprojection functor only")
+
+
 class HipBackend:
     """The product backend: include/mpsfm_hip.h through ctypes."""
 
@@ -219,7 +234,7 @@ class Optimizer(BaseClass):
         n_cams = len(image_ids)
         cam_ids = [rec.images[i].camera_id for i in image_ids]
         uniq = sorted(set(cam_ids))
-        intr = np.array([np.asarray(rec.rec.cameras[c].params, np.float64)[:4] for c in uniq]).reshape(-1, 4)
+        intr = np.array([pinhole_params(rec.rec.cameras[c]) for c in uniq]).reshape(-1, 4)
         prob = BAProblem(
             cam_quat=np.array([rec.images[i].cam_from_world.rotation.quat for i in image_ids]).reshape(-1, 4),
             cam_t=np.array([rec.images[i].cam_from_world.translation for i in image_ids]).reshape(-1, 3),
@@ -288,7 +303,7 @@ class Optimizer(BaseClass):
             cam_quat=np.array([rec.images[i].cam_from_world.rotation.quat for i in image_ids]).reshape(-1, 4),
             cam_t=np.array([rec.images[i].cam_from_world.translation for i in image_ids]).reshape(-1, 3),
             pts=np.array([rec.points3D[p].xyz for p in point_ids]).reshape(-1, 3),
-            cam_intr=np.array([np.asarray(rec.rec.cameras[c].params, np.float64)[:4] for c in uniq]).reshape(-1, 4),
+            cam_intr=np.array([pinhole_params(rec.rec.cameras[c]) for c in uniq]).reshape(-1, 4),
             cam_intr_idx=np.array([uniq.index(c) for c in cam_ids], np.int32), pose_const=pose_const, pt_const=pt_const,
             obs_cam=np.array(obs_cam, np.int32), obs_pt=np.array(obs_pt, np.int32),
             obs_xy=np.array(obs_xy, np.float64).reshape(-1, 2), reproj_loss_type=LOSS_TRIVIAL,

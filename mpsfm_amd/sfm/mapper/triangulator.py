@@ -16,28 +16,33 @@ import numpy as np
 from ...baseclass import BaseClass
 from ...problem import Tracks
 from ...utils.geometry import has_point_positive_depth
+from .bundle_adjustment import pinhole_params
 
 
-def tracks_from_scene(scene, point3D_ids) -> tuple[Tracks, list]:
-    """CSR tracks of the given points over the images of a scene (cameras indexed by image order)."""
+def tracks_from_scene(scene, point3D_ids, keep_elements=False) -> tuple[Tracks, list]:
+    """CSR tracks of the given points over the images of a scene (cameras indexed by image order).  With
+    `keep_elements` the returned Tracks carries `.elements`: (image_id, point2D_idx) per track element."""
     imids = sorted(scene.images.keys())
     cam_of = {imid: i for i, imid in enumerate(imids)}
     cam_ids = [scene.images[i].camera_id for i in imids]
     uniq = sorted(set(cam_ids))
-    start, el_cam, el_xy = [0], [], []
+    start, el_cam, el_xy, elements = [0], [], [], []
     for pid in point3D_ids:
         for el in scene.points3D[int(pid)].track.elements:
             el_cam.append(cam_of[el.image_id])
             el_xy.append(np.asarray(scene.images[el.image_id].points2D[el.point2D_idx].xy, np.float64))
+            if keep_elements:
+                elements.append((int(el.image_id), int(el.point2D_idx)))
         start.append(len(el_cam))
     tr = Tracks(
         cam_quat=np.array([scene.images[i].cam_from_world.rotation.quat for i in imids]).reshape(-1, 4),
         cam_t=np.array([scene.images[i].cam_from_world.translation for i in imids]).reshape(-1, 3),
-        cam_intr=np.array([np.asarray(scene.rec.cameras[c].params, np.float64)[:4] for c in uniq]).reshape(-1, 4),
+        cam_intr=np.array([pinhole_params(scene.rec.cameras[c]) for c in uniq]).reshape(-1, 4),
         cam_intr_idx=np.array([uniq.index(c) for c in cam_ids], np.int32),
         track_start=np.array(start, np.int64), el_cam=np.array(el_cam, np.int32),
         el_xy=np.array(el_xy, np.float64).reshape(-1, 2),
     )
+    tr.elements = elements
     return tr, imids
 
 
@@ -85,6 +90,7 @@ class MpsfmTriangulator(BaseClass, ColmapTriangulatorWrapper):
     def _init(self, mpsfm_rec, correspondences_graph=None, engine=None, **kwargs):
         self.mpsfm_rec = mpsfm_rec
         self._triangulator = engine  # IncrementalTriangulator-compatible object (graph logic)
+        self.device = int(kwargs.get("device", 0))
         opts = self.conf.colmap_options
         self.options = dict(opts) if isinstance(opts, dict) else {}
 
@@ -124,12 +130,14 @@ class MpsfmTriangulator(BaseClass, ColmapTriangulatorWrapper):
 
     def lift_low_parallax(self, point3D_ids, min_angle):
         """Replace the points among `point3D_ids` whose largest triangulation angle is below
-        `min_angle` degrees by points lifted from the first activated depth map of their track."""
-        ids = np.array(list(point3D_ids))
+        `min_angle` degrees by points lifted from the first activated depth map of their track
+        (reference :49-83: the mask of mpsfm_rec.find_points3D_with_small_triangulation_angle, here
+        taken from the HIP batch kernel directly)."""
+        ids = np.array([int(p) for p in point3D_ids if int(p) in self.mpsfm_rec.points3D], dtype=np.int64)
         if len(ids) == 0:
             return []
-        risky = self.mpsfm_rec.find_points3D_with_small_triangulation_angle(min_angle=min_angle, point3D_ids=ids)
-        return self._lift_points(ids[risky])
+        ang, _, _ = track_quality(self.mpsfm_rec, ids, self.device)
+        return self._lift_points(ids[ang < np.deg2rad(float(min_angle))])
 
     def triangulate_image(self, imid, **kwargs) -> bool:
         self._require_engine()

@@ -24,6 +24,7 @@ import numpy as np
 
 from ...synthetic import R_from_quat, quat_from_R
 from ...utils.geometry import project3D_colmap
+from .observations import HipObservationManager
 from .priorutils import PriorUtils
 
 INVALID_POINT3D = 18446744073709551615  # pycolmap's kInvalidPoint3DId (reference triangulator.py:109)
@@ -97,6 +98,7 @@ class Track:
 class NumpyPoint3D:
     def __init__(self, xyz, track=None):
         self.xyz = np.array(xyz, dtype=np.float64)
+        self.error = -1.0
         self.track = track if track is not None else Track()
 
 
@@ -144,8 +146,16 @@ class NumpyDepth(PriorUtils):
         self.camera = camera
         self.kps = kps
         self.scale = 1.0
+        self.shift = 0.0
         self.activated = True
         self.uncertainty_update = self.uncertainty_at_kps(kps)  # depth.py:130
+
+    def reset(self):
+        """back to the unscaled, not activated prior (reference depth.py:132-140)"""
+        self.data_prior = self.data_prior / self.scale
+        self.uncertainty = self.uncertainty / self.scale**2
+        self.uncertainty_update = self.uncertainty_at_kps(self.kps)
+        self.scale, self.shift, self.activated, self.data = 1.0, 0.0, False, None
 
 
 class NumpyImage:
@@ -161,6 +171,10 @@ class NumpyImage:
 
     def get_observation_point2D_idxs(self):
         return np.flatnonzero(self.kp_point3D != INVALID_POINT3D)
+
+    @property
+    def num_points3D(self):
+        return int((self.kp_point3D != INVALID_POINT3D).sum())
 
     def keypoint_coordinates(self, idxs):
         return self.kps[np.asarray(idxs, dtype=np.int64)]
@@ -211,13 +225,29 @@ class ObservationManager:
         del s.points3D[pid]
         s.point_covs.data.pop(pid, None)
 
-    def find_small_angle_points_mask(self, min_angle_deg, point3D_ids):
-        """True where the largest pairwise triangulation angle of the track is below min_angle
-        (the fork's ObservationManager.find_small_angle_points_mask, reference points3D_utils.py:64-71)."""
-        from ..mapper.triangulator import track_quality
+    def delete_observation(self, image_id, point2D_idx):
+        """COLMAP ObservationManager::DeleteObservation: a track of length <= 2 goes away with its point."""
+        s = self.scene
+        pid = int(s.images[image_id].kp_point3D[point2D_idx])
+        track = s.points3D[pid].track
+        if track.length() <= 2:
+            self.delete_point3D(pid)
+            return
+        track.elements = [el for el in track.elements if not (el.image_id == image_id and el.point2D_idx == point2D_idx)]
+        s.images[image_id].kp_point3D[point2D_idx] = INVALID_POINT3D
 
-        ang, _, _ = track_quality(self.scene, list(point3D_ids))
-        return ang < np.deg2rad(min_angle_deg)
+    def deregister_image(self, image_id):
+        self.scene.images[image_id].has_pose = False
+
+    def filter_images(self, min_focal_length_ratio, max_focal_length_ratio, max_extra_param):
+        """COLMAP deregisters images without points or with degenerate intrinsics; the stand-in has fixed PINHOLE
+        cameras, so only the first rule applies."""
+        n = 0
+        for imid, im in self.scene.registered_images.items():
+            if len(im.get_observation_point2D_idxs()) == 0:
+                self.deregister_image(imid)
+                n += 1
+        return n
 
 
 class NumpyReconstruction:
@@ -225,7 +255,8 @@ class NumpyReconstruction:
         self.images: dict[int, NumpyImage] = {}
         self.points3D: dict[int, NumpyPoint3D] = {}
         self.rec = _Rec()
-        self.obs = ObservationManager(self)
+        # bookkeeping by the stand-in manager, per-track numerics by the HIP kernels (as on the real pycolmap object)
+        self.obs = HipObservationManager(self, ObservationManager(self))
         self.point_covs = PointCovs()
         self._next_point3D_id = 1
 
@@ -272,6 +303,28 @@ class NumpyReconstruction:
 
     def rotate_covs_to_cam(self, Covs_world, imid):
         return self.rotate_covs(Covs_world, self.images[imid].cam_from_world.rotation.matrix().T)
+
+    # -- depth bookkeeping of the reference's DepthUtils mixin (reconstruction/mixins/depth_utils.py:52-92) ------
+    def activate_depths(self, imids):
+        for imid in imids:
+            d = self.images[imid].depth
+            if not d.activated:
+                d.activated = True
+                d.data = d.data_prior.copy()
+
+    def rescale_all(self, shift_scales):
+        for imid, (shift, scale) in shift_scales.items():
+            d = self.images[imid].depth
+            d.data_prior = d.data_prior * scale + shift
+            d.scale *= scale
+            d.shift = d.shift * scale + shift
+            d.uncertainty = d.uncertainty * scale**2
+        for imid, (shift, scale) in shift_scales.items():
+            d = self.images[imid].depth
+            d.uncertainty_update = d.uncertainty_update * scale**2
+
+    def reg_image_ids(self):
+        return [i for i, im in self.images.items() if im.has_pose]
 
     def find_points3D_with_small_triangulation_angle(self, min_angle, point3D_ids):
         return np.array(self.obs.find_small_angle_points_mask(float(min_angle), point3D_ids))

@@ -232,3 +232,51 @@ def algorithmic_bytes_sweep(prob: BAProblem) -> int:
     56 B per camera (pose read) and 8 B per entry of the reduced camera system written once."""
     n = 6 * prob.n_cams
     return 24 * prob.n_obs + 32 * prob.n_dobs + 24 * prob.n_pts + 56 * prob.n_cams + 8 * n * n
+
+
+def local_window(prob: BAProblem, window_cams, ref_cam: int, max_track: int = 15):
+    """The flat problem of ONE local bundle adjustment cut out of a global flat problem, as
+    ``Optimizer.__build_problem(mode="local")`` assembles it on the reference's objects
+    (mpsfm/sfm/mapper/bundle_adjustment.py:85-122, bundle from mapper/base.py:729-749):
+
+      * the window's images are the configuration: first one constant, second one with translation x fixed;
+      * every observation of a window image gives a reprojection block (and its depth block, if any);
+      * landmarks seen by `ref_cam` with a track shorter than `max_track` are explicitly variable: their observations in
+        images outside the window come along with those poses constant;
+      * any other landmark whose track is not completely inside the problem is constant.
+
+    Returns (local BAProblem, cam_ids [local camera -> global camera], pt_ids [local landmark -> global landmark])."""
+    window_cams = [int(c) for c in window_cams]
+    n_cfg = len(window_cams)
+    in_cfg = np.zeros(prob.n_cams, bool)
+    in_cfg[window_cams] = True
+    track_len = np.bincount(prob.obs_pt, minlength=prob.n_pts)
+    sel = in_cfg[prob.obs_cam]
+    seen_by_ref = np.zeros(prob.n_pts, bool)
+    seen_by_ref[prob.obs_pt[prob.obs_cam == ref_cam]] = True
+    explicit = seen_by_ref & (track_len < max_track)
+    sel_all = sel | explicit[prob.obs_pt]
+    cams_extra = np.setdiff1d(np.unique(prob.obs_cam[sel_all]), window_cams)
+    cam_ids = np.concatenate([np.array(window_cams, np.int64), cams_extra.astype(np.int64)])
+    cam_of = np.full(prob.n_cams, -1, np.int64)
+    cam_of[cam_ids] = np.arange(len(cam_ids))
+    pt_ids = np.unique(prob.obs_pt[sel_all])
+    pt_of = np.full(prob.n_pts, -1, np.int64)
+    pt_of[pt_ids] = np.arange(len(pt_ids))
+    n_in = np.bincount(prob.obs_pt[sel_all], minlength=prob.n_pts)
+    pose_const = np.ones(len(cam_ids), np.uint8)
+    pose_const[1:n_cfg] = 0
+    dsel = in_cfg[prob.dobs_cam] & (pt_of[prob.dobs_pt] >= 0) if prob.n_dobs else np.zeros(0, bool)
+    local = BAProblem(
+        cam_quat=prob.cam_quat[cam_ids].copy(), cam_t=prob.cam_t[cam_ids].copy(), pts=prob.pts[pt_ids].copy(),
+        cam_intr=prob.cam_intr, cam_intr_idx=prob.cam_intr_idx[cam_ids], pose_const=pose_const,
+        pt_const=(track_len[pt_ids] > n_in[pt_ids]).astype(np.uint8),
+        obs_cam=cam_of[prob.obs_cam[sel_all]].astype(np.int32), obs_pt=pt_of[prob.obs_pt[sel_all]].astype(np.int32),
+        obs_xy=prob.obs_xy[sel_all], gauge_axis_cam=1 if n_cfg > 1 else -1,
+        reproj_loss_type=prob.reproj_loss_type, reproj_loss_scale=prob.reproj_loss_scale,
+        reproj_loss_magnitude=prob.reproj_loss_magnitude,
+        dobs_cam=cam_of[prob.dobs_cam[dsel]].astype(np.int32), dobs_pt=pt_of[prob.dobs_pt[dsel]].astype(np.int32),
+        dobs_depth=prob.dobs_depth[dsel], dobs_magnitude=prob.dobs_magnitude[dsel], dobs_param=prob.dobs_param[dsel],
+        depth_loss_type=prob.depth_loss_type,
+    )
+    return local, cam_ids, pt_ids

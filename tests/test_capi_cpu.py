@@ -80,3 +80,64 @@ def test_integration_entry_points_validate_arguments_first():
         with pytest.raises(capi.MpsfmHipError) as e:
             capi.integrate_depth(*args, m["kps"], m["depth3d"], m["zvars3d"])
         assert e.value.code == -2
+
+
+def test_null_arrays_are_einval_not_a_crash():
+    """mpsfm_point_covs / mpsfm_triangulate_tracks / mpsfm_filter_tracks check their pointers like
+    mpsfm_ba_solve does (a C caller passing NULL gets MPSFM_EINVAL, not a segfault)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from mpsfm_amd.problem import CProblem, CState, CTracks
+
+    L = capi.lib()
+    prob, _ = make_scene(3, 30, False, seed=0)
+    covs = np.zeros((prob.n_pts, 3, 3))
+    for field in ("obs_cam", "obs_pt", "obs_xy", "cam_intr_idx", "cam_intr"):
+        cp, cs = prob.c_problem(), prob.c_state()
+        setattr(cp, field, None)
+        assert L.mpsfm_point_covs(C.byref(cp), C.byref(cs), 0, covs.ctypes.data) == -1, field
+    for field in ("cam_quat_xyzw", "cam_t", "pts"):
+        cp, cs = prob.c_problem(), prob.c_state()
+        setattr(cs, field, None)
+        assert L.mpsfm_point_covs(C.byref(cp), C.byref(cs), 0, covs.ctypes.data) == -1, field
+    assert L.mpsfm_point_covs(None, None, 0, None) == -1
+    start = np.array([0, 2, 4], np.int64)
+    el_cam = np.array([0, 1, 1, 2], np.int32)
+    el_xy = np.zeros((4, 2))
+    xyz = np.zeros((2, 3))
+
+    def tracks():
+        t = CTracks()
+        t.n_cams, t.n_tracks, t.n_intr = 3, 2, 1
+        t.cam_quat_xyzw, t.cam_t = prob.cam_quat.ctypes.data, prob.cam_t.ctypes.data
+        t.cam_intr, t.cam_intr_idx = prob.cam_intr.ctypes.data, prob.cam_intr_idx.ctypes.data
+        t.track_start, t.el_cam, t.el_xy = start.ctypes.data, el_cam.ctypes.data, el_xy.ctypes.data
+        return t
+
+    for field in ("cam_quat_xyzw", "cam_t", "cam_intr", "cam_intr_idx", "track_start", "el_cam", "el_xy"):
+        t = tracks()
+        setattr(t, field, None)
+        assert L.mpsfm_triangulate_tracks(C.byref(t), 0, xyz.ctypes.data) == -1, field
+        assert L.mpsfm_filter_tracks(C.byref(t), xyz.ctypes.data, 0, None, None, None) == -1, field
+    t = tracks()
+    assert L.mpsfm_triangulate_tracks(C.byref(t), 0, None) == -1
+
+
+def test_non_pinhole_camera_models_are_refused():
+    import types
+
+    import numpy as np
+
+    from mpsfm_amd.sfm.mapper.bundle_adjustment import pinhole_params
+
+    cam = types.SimpleNamespace(params=np.array([1200.0, 1190.0, 800.0, 600.0]))
+    np.testing.assert_array_equal(pinhole_params(cam), cam.params)
+    cam.model = types.SimpleNamespace(name="PINHOLE")
+    np.testing.assert_array_equal(pinhole_params(cam), cam.params)
+    simple = types.SimpleNamespace(params=np.array([1000.0, 800.0, 600.0]), model=types.SimpleNamespace(name="SIMPLE_PINHOLE"))
+    np.testing.assert_array_equal(pinhole_params(simple), [1000.0, 1000.0, 800.0, 600.0])
+    for name in ("SIMPLE_RADIAL", "OPENCV"):
+        with pytest.raises(NotImplementedError):
+            pinhole_params(types.SimpleNamespace(params=np.zeros(8), model=types.SimpleNamespace(name=name)))

@@ -488,3 +488,16 @@ def test_inverse_propagation_equals_grouped_back_substitution(monkeypatch):
     for radius in (1e4, 1e-1):
         a, b = ys[("1", radius)], ys[("0", radius)]
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-10 * np.abs(b).max())
+
+
+def test_aborted_solve_does_not_hand_live_blocks_to_another_handle():
+    """free_handle waits for the handle's streams before its blocks go back to the process-wide
+    cache.  A solve aborted by a failing all-reduce hook on one thread, a clean solver on another, MPSFM_POISON=1."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPSFM_POISON="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_poison_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -168,3 +168,36 @@ def test_unknown_conf_key_is_rejected(scene):
     sc, _, _ = scene
     with pytest.raises(KeyError):
         Optimizer({"not_a_key": 1}, sc, None, backend=OracleBackend())
+
+
+def test_local_window_helper_equals_the_shims_local_assembly():
+    """mpsfm_amd.synthetic.local_window (used by the full-size C5 GPU test) cuts the same reprojection problem out of a
+    flat global problem as Optimizer._build_problem(mode="local") assembles from the scene objects."""
+    from mpsfm_amd.synthetic import local_window
+
+    prob, truth = make_scene(12, 900, True, seed=29)
+    sc = scene_from_problem(prob, truth, seed=2)
+    ids = sorted(sc.images)
+    ref = ids[5]
+    optim = {ids[4], ids[5], ids[6], ids[3]}
+    bundle = {"ref_id": ref, "optim_ids": optim, "constpoints": set(),
+              "pts3D": set(sc.images[ref].point3D_ids(sc.images[ref].get_observation_point2D_idxs()))}
+    flat, _ = Optimizer({}, sc, None, backend=OracleBackend())._build_problem(bundle, False, True, mode="local", solve=False)
+    window = [i - ids[0] for i in list(optim)]  # same order as the shim's list(bundle["optim_ids"])
+    loc, cams, pts = local_window(prob, window, ref - ids[0])
+    p = flat.prob
+    assert [i - ids[0] for i in flat.image_ids[:4]] == window and sorted(i - ids[0] for i in flat.image_ids) == sorted(cams.tolist())
+    assert p.n_obs == loc.n_obs and p.n_pts == loc.n_pts and p.gauge_axis_cam == loc.gauge_axis_cam == 1
+    np.testing.assert_array_equal(p.pose_const[:4], loc.pose_const[:4])
+    assert p.pose_const[4:].all() and loc.pose_const[4:].all()
+    pid_of = sc._pid_of_problem_point
+    const_shim = {pid: int(c) for pid, c in zip(flat.point_ids, p.pt_const)}
+    const_loc = {pid_of[int(g)]: int(c) for g, c in zip(pts, loc.pt_const)}
+    assert const_shim == const_loc and 0 < sum(const_loc.values()) < len(const_loc)
+
+    def blocks(pr, cam_ids, pt_ids):
+        return sorted((int(cam_ids[c]), int(pt_ids[q]), float(x), float(y)) for c, q, (x, y) in zip(pr.obs_cam, pr.obs_pt, pr.obs_xy))
+
+    shim_blocks = blocks(p, [i - ids[0] for i in flat.image_ids], flat.point_ids)
+    loc_blocks = blocks(loc, cams, [pid_of[int(g)] for g in pts])
+    assert shim_blocks == loc_blocks
