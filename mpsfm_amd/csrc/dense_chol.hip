@@ -112,198 +112,142 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 
-// Cholesky of a 32x32 tile held one row per lane (lane i and lane i+32 both hold row i).
-// Right-looking, software-pipelined by one column so that the only cross-lane traffic on the
-// dependent chain is two readlane broadcasts:
-//   chain(j)  d = a_jj (readlane), inv = rsqrt(d), t = a_ij / d, the NEXT pivot column gets its
-//             update right away (a[j+1] -= t * a_{j+1,j}, readlane), column j (unscaled) goes to LDS
-//   bulk(j-1) a[c] -= t_{j-1} * a_{c,j-1} for c >= j+1 with the column broadcast from LDS; its
-//             reads are issued before chain(j) and consumed after it, hiding the LDS round trip.
-// On return lane i holds row i of L in a[0..i]; s_inv[j] = 1 / L[j][j].
 #define MPSFM_PIN(x) asm volatile("" : "+v"(x))
 
-constexpr int kPanel = 16;  // columns factored per register panel; the rest of the tile is updated by MFMA
+// ---- stacked panel factorisation: Cholesky of the diagonal tile and the solve of the workgroup's own tile in ONE wave --
+// Lane i < 32 holds row i of the (updated, symmetric, both triangles valid) diagonal tile D, lane 32 + i holds row i of
+// the workgroup's own tile X (or of the identity for the workgroup that owns the diagonal tile).  The column
+// operations of a Cholesky panel factorisation of the stacked 64 x 32 matrix [D; X] are the same for both halves —
+//   l_iJ = a_iJ / sqrt(d_J),   a_ic -= l_iJ l_cJ  (c > J)
+// — so the triangular solve X L^-T costs no instruction of its own and needs no second wave, no hand-shake and no
+// LDS traffic per column.
+//
+// One wave issues one instruction per ~4-5 cycles (fp64 multiply-add: 5.5, v_readlane: 4.9, v_rsq_f64 / v_rcp_f64: 16.5;
+// a dependent fp64 op waits 8 — scripts/micro/f64_issue.hip), and the 496 rank-1 multiply-adds per lane are fixed, so
+// the factorisation is bound by its INSTRUCTION COUNT: per column one transcendental (v_rsq_f64 + one cubic step
+// y = y0 (1 + e/2 + 3e^2/8), e = 1 - d y0^2: v_rsq_f64 is good to ~2^-26, the step to ~e^3), the scaling l = a y, and
+// the rank-1 update with the multipliers l_cJ broadcast
+//   inside a panel of kSP columns   by v_readlane (they sit in lane c, register J — the matrix is symmetric),
+//   beyond the panel                from LDS: after a panel its kSP columns of L (rows < 32) are written once and come
+//                                   back as uniform-address ds_read_b128; the next panel's columns get the rank-kSP
+//                                   update at once, the columns beyond get it one column of L per column of the next
+//                                   panel (filling the issue slots its dependent chain leaves empty).
+constexpr int kSP = 8;
 
-// bulk(J-1) slot SLOT: up to Q multiply-adds a[c] -= tprev * col[c], c = J+1+SLOT*Q ..
-template <int J, int SLOT, int Q, int NF>
-__device__ __forceinline__ void potrf_bulk(double (&a)[kPanel], const double (&col)[kPanel], double tprev) {
+// Broadcast reads of L rows from LDS are issued in ONE batch well before their use, as explicit ds_read_b128 with one
+// s_waitcnt in front of the consumers: left to itself the compiler issues two or three reads and waits for them
+// (s_waitcnt lgkmcnt(0)) ten times per panel boundary, exposing the LDS latency each time (0.45 us per boundary
+// measured).  LDS operations of a wave return in order, so the compiler's own counted waits stay correct beside these.
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const double* p) { return (uint32_t)(uintptr_t)p; }  // low 32 bits of a __shared__ address = LDS offset
+template <int N>
+__device__ __forceinline__ void lds_row_load(uint32_t addr, v2d (&m)[N]) {
 #pragma unroll
-  for (int u = 0; u < Q; ++u) {
-    constexpr int kBase = J + 1 + SLOT * Q;
-    if (SLOT * Q + u < NF) {
-      a[kBase + u] -= tprev * col[kBase + u];
-      MPSFM_PIN(a[kBase + u]);
-    }
-  }
+  for (int q = 0; q < N; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(m[q]) : "v"(addr), "n"(16 * q));
 }
+// the loaded values pass through the wait, so no consumer can be scheduled in front of it
+__device__ __forceinline__ void lds_wait(v2d (&m)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3])); }
+__device__ __forceinline__ void lds_wait(v2d (&m)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
+}
+__device__ __forceinline__ void lds_wait(v2d (&m)[1]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m[0])); }
 
-// Column J of a 16-column register panel (tile columns OFF .. OFF+15; lane i holds row i of the tile,
-// a[c] = A[i][OFF + c]).  Right-looking inside the panel, software-pipelined by one column:
-//   chain(J)  d = pivot (readlane), 1/d by v_rcp_f64 + Newton, t = a_iJ / d, the NEXT pivot column gets
-//             its update right away (readlane), the unscaled column goes to LDS
-//   bulk(J-1) a[c] -= t_{J-1} * a_{OFF+c, J-1} for the remaining panel columns, column broadcast from LDS
-// Source order == issue order (values are pinned with empty volatile asm statements): the dependent
-// ops of chain(J) are interleaved with the independent multiply-adds of bulk(J-1).
-// Publishes column OFF+J of L (s_Lt), 1/L[jj][jj] (s_inv) and the progress counter for the TRSM wave.
-template <int J, int OFF>
-__device__ __forceinline__ void potrf_panel_col(double (&a)[kPanel], int lane, double* s_inv, double (*s_col)[kTile],
-                                                double* s_Lt, int* s_ready, double& tprev, bool& ok) {
-  constexpr int NF = (J >= 1) ? (kPanel - 1 - J) : 0;
-  constexpr int Q = (NF + 9) / 10;
-  double col[kPanel];
-  if (J >= 1) {
-#pragma unroll
-    for (int c = J + 1; c < kPanel; ++c) col[c] = s_col[(J - 1) & 1][OFF + c];
-  }
-  const double d = readlane_f64(a[J], OFF + J);
+template <int J0, int J>
+__device__ __forceinline__ void stacked_col(double (&a)[kTile], const double* s_P, bool& ok) {
+  constexpr int C = J0 + J;
+  constexpr bool kHasFar = (J0 > 0) && (J0 + kSP < kTile);  // the previous panel still owes the columns beyond this panel
+  constexpr int F0 = J0 + kSP, NF = kHasFar ? (kTile - F0) / 2 : 1;
+  // column J of the previous panel for the far columns [F0, 32): requested first, consumed after the chain below
+  v2d mf[NF];
+  if constexpr (kHasFar) lds_row_load<NF>(lds_addr(s_P + J * kTile + F0), mf);
+  const double d = readlane_f64(a[C], C);
   ok = ok && (d > 0.0) && isfinite(d);
-  double r = __builtin_amdgcn_rcp(d); MPSFM_PIN(r);
-  double y = __builtin_amdgcn_rsq(d); MPSFM_PIN(y);          // off-chain: 1/sqrt(d) for L itself
-  potrf_bulk<J, 0, Q, NF>(a, col, tprev);
-  double e = __builtin_fma(-d, r, 1.0); MPSFM_PIN(e);
-  double hd = 0.5 * d; MPSFM_PIN(hd);
-  potrf_bulk<J, 1, Q, NF>(a, col, tprev);
-  r = __builtin_fma(r, e, r); MPSFM_PIN(r);
-  double w = -hd * y; MPSFM_PIN(w);
-  potrf_bulk<J, 2, Q, NF>(a, col, tprev);
-  e = __builtin_fma(-d, r, 1.0); MPSFM_PIN(e);                // second step: v_rcp_f64 alone is ~2^-26
-  double f = __builtin_fma(w, y, 1.5); MPSFM_PIN(f);
-  potrf_bulk<J, 3, Q, NF>(a, col, tprev);
-  r = __builtin_fma(r, e, r); MPSFM_PIN(r);
-  y = y * f; MPSFM_PIN(y);
-  potrf_bulk<J, 4, Q, NF>(a, col, tprev);
-  double t = a[J] * r; MPSFM_PIN(t);                          // a_iJ / d
-  w = -hd * y; MPSFM_PIN(w);
-  potrf_bulk<J, 5, Q, NF>(a, col, tprev);
-  if (J + 1 < kPanel) {
-    a[(J + 1) % kPanel] -= t * readlane_f64(a[J], OFF + (J + 1) % kPanel);
-    MPSFM_PIN(a[(J + 1) % kPanel]);
-  }
-  f = __builtin_fma(w, y, 1.5); MPSFM_PIN(f);
-  potrf_bulk<J, 6, Q, NF>(a, col, tprev);
-  const double inv = y * f;
-  potrf_bulk<J, 7, Q, NF>(a, col, tprev);
-  const double l = a[J] * inv;                                // l_iJ = a_iJ / sqrt(d)
-  potrf_bulk<J, 8, Q, NF>(a, col, tprev);
-  if (lane < kTile) { s_col[J & 1][lane] = a[J]; s_Lt[(OFF + J) * kTile + lane] = l; }
-  if (lane == 0) {
-    s_inv[OFF + J] = inv;
-    // column OFF+J of L and its 1/diag are in LDS: the TRSM wave may use them (DS ops of a wave complete in order)
-    __hip_atomic_store(s_ready, OFF + J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  a[J] = l;
-  potrf_bulk<J, 9, Q, NF>(a, col, tprev);
-  tprev = t;
-  if constexpr (J + 1 < kPanel) potrf_panel_col<J + 1, OFF>(a, lane, s_inv, s_col, s_Lt, s_ready, tprev, ok);
-}
-
-// Blocked Cholesky of the 32x32 tile in s_T (row stride 33, both triangles valid) by one wave:
-//   panel 0  columns 0..15 of all 32 rows in registers (factors A11 and solves A21 in one go)
-//   update   A22 -= L21 L21^T with four v_mfma_f64_16x16x4_f64 (operands read back from s_Lt)
-//   panel 1  columns 16..31 (rows 16..31 matter)
-// L^T ends up in s_Lt (s_Lt[c*32 + r] = L[r][c], r >= c), 1/diag in s_inv.
-__device__ __forceinline__ bool potrf_tile(double (*s_T)[kTile + 1], int lane, double* s_inv, double (*s_col)[kTile], double* s_Lt,
-                                           int* s_ready) {
-  bool ok = true;
-  const int row = lane & 31;
-  {
-    double a[kPanel];
+  const double y0 = __builtin_amdgcn_rsq(d);
+  const double h = d * y0;
+  const double e = __builtin_fma(-h, y0, 1.0);
+  const double p = __builtin_fma(0.375 * e, e, 0.5 * e);
+  const double y = __builtin_fma(y0, p, y0);
+  const double l = a[C] * y;
+  a[C] = l;
 #pragma unroll
-    for (int c = 0; c < kPanel; ++c) a[c] = s_T[row][c];
-    double tprev = 0.0;
-    potrf_panel_col<0, 0>(a, lane, s_inv, s_col, s_Lt, s_ready, tprev, ok);
-  }
-  {
-    const int i = lane & 15, kg = lane >> 4;
-    v4d acc;
+  for (int c = J + 1; c < kSP; ++c) a[J0 + c] = __builtin_fma(-l, readlane_f64(l, J0 + c), a[J0 + c]);
+  if constexpr (kHasFar) {
+    const double lk = a[J0 - kSP + J];
+    lds_wait(mf);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = s_T[kPanel + kg + 4 * r][kPanel + i];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const double op = s_Lt[(4 * s + kg) * kTile + kPanel + i];  // L21[i][4s + kg]
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-op, op, acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s_T[kPanel + kg + 4 * r][kPanel + i] = acc[r];
-  }
-  {
-    double a[kPanel];
-#pragma unroll
-    for (int c = 0; c < kPanel; ++c) a[c] = s_T[row][kPanel + c];
-    double tprev = 0.0;
-    potrf_panel_col<0, kPanel>(a, lane, s_inv, s_col, s_Lt, s_ready, tprev, ok);
-  }
-  return ok;
-}
-
-// x <- x L^-T for the row held by this lane, columns [C0, C1): L^T is read from LDS as
-// s_Lt[c*32 + k] = L[k][c] (uniform addresses: broadcast reads), 1/L[c][c] from s_inv.  The reads of
-// column c+1 are issued before the multiply-adds of column c.
-template <int C0, int C1>
-__device__ __forceinline__ void trsm_cols(double (&x)[kTile], const double* s_Lt, const double* s_inv) {
-  double lt[2][kTile];
-  double iv[2];
-#pragma unroll
-  for (int k = C0 + 1; k < kTile; ++k) lt[C0 & 1][k] = s_Lt[C0 * kTile + k];
-  iv[C0 & 1] = s_inv[C0];
-#pragma unroll
-  for (int c = C0; c < C1; ++c) {
-    if (c + 1 < C1) {
-#pragma unroll
-      for (int k = c + 2; k < kTile; ++k) lt[(c + 1) & 1][k] = s_Lt[(c + 1) * kTile + k];
-      iv[(c + 1) & 1] = s_inv[c + 1];
-    }
-    x[c] *= iv[c & 1];
-#pragma unroll
-    for (int k = c + 1; k < kTile; ++k) {
-      x[k] -= x[c] * lt[c & 1][k];
-      asm volatile("" : "+v"(x[k]));
+    for (int q = 0; q < NF; ++q) {
+      a[F0 + 2 * q] = __builtin_fma(-lk, mf[q].x, a[F0 + 2 * q]);
+      a[F0 + 2 * q + 1] = __builtin_fma(-lk, mf[q].y, a[F0 + 2 * q + 1]);
     }
   }
+  if constexpr (J + 1 < kSP) stacked_col<J0, J + 1>(a, s_P, ok);
 }
 
-// The solve runs BEHIND the factorising wave: the first 16 columns (76 % of the multiply-adds) start
-// as soon as the progress counter says columns 0..15 of L are in LDS, i.e. under the second half of
-// the factorisation; only the last 16 columns wait for the factor to be complete.
-__device__ __forceinline__ void trsm_row(double (&x)[kTile], const double* s_Lt, const double* s_inv, int* s_ready) {
-  while (__hip_atomic_load(s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kTile / 2) __builtin_amdgcn_s_sleep(2);
-  trsm_cols<0, kTile / 2>(x, s_Lt, s_inv);
-  while (__hip_atomic_load(s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kTile) __builtin_amdgcn_s_sleep(2);
-  trsm_cols<kTile / 2, kTile>(x, s_Lt, s_inv);
+template <int J0>
+__device__ __forceinline__ void stacked_panel(double (&a)[kTile], int lane, double* s_P, bool& ok) {
+  stacked_col<J0, 0>(a, s_P, ok);
+  if constexpr (J0 + kSP < kTile) {
+    // columns J0 .. J0+kSP-1 of L, rows < 32: s_P[k][c] = L[c][J0 + k].  The far updates of the previous panel read
+    // s_P during this panel: they are all issued by now (one wave, DS operations complete in order).
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kTile) {
+#pragma unroll
+      for (int k = 0; k < kSP; ++k) s_P[k * kTile + lane] = a[J0 + k];
+    }
+    // one wave: its DS operations complete in order, so the reads below see the stores above; only the compiler must
+    // be kept from moving them (workgroup-scope fences here cost ~0.3 us per panel boundary)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // rank-kSP update of the next panel's columns (its chain starts on them): all reads first, two batches
+    {
+      // 4 reads per column of L; at most 15 LDS operations can be in flight, so two halves of 16 reads
+      v2d m[kSP][kSP / 2];
+#pragma unroll
+      for (int k = 0; k < kSP; ++k) {
+        if (k == kSP / 2) {
+#pragma unroll
+          for (int kk = 0; kk < kSP / 2; ++kk) lds_wait(m[kk]);
+        }
+        lds_row_load<kSP / 2>(lds_addr(s_P + k * kTile + J0 + kSP), m[k]);
+      }
+#pragma unroll
+      for (int kk = kSP / 2; kk < kSP; ++kk) lds_wait(m[kk]);
+#pragma unroll
+      for (int k = 0; k < kSP; ++k) {
+#pragma unroll
+        for (int q = 0; q < kSP / 2; ++q) {
+          a[J0 + kSP + 2 * q] = __builtin_fma(-a[J0 + k], m[k][q].x, a[J0 + kSP + 2 * q]);
+          a[J0 + kSP + 2 * q + 1] = __builtin_fma(-a[J0 + k], m[k][q].y, a[J0 + kSP + 2 * q + 1]);
+        }
+      }
+    }
+    stacked_panel<J0 + kSP>(a, lane, s_P, ok);
+  }
 }
 
-// half-tile variants (rows 16 mi .. 16 mi + 15) for the two waves of a trailing-update workgroup
-__device__ __forceinline__ void half_load_acc(const double* __restrict__ T, int lane, int mi, v4d acc[2]) {
+// ---- 16 x 16 quadrants of a 32 x 32 tile in the accumulator layout of v_mfma_f64_16x16x4_f64 (one per wave) -----------
+// element r of lane l sits at row 16 mi + (l >> 4) + 4 r, column 16 ni + (l & 15)
+template <typename Ptr>
+__device__ __forceinline__ void quad_load(Ptr T, int ld, int lane, int mi, int ni, v4d& acc) {
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[ni][r] = T[(16 * mi + (lane >> 4) + 4 * r) * kTile + 16 * ni + (lane & 15)];
+  for (int r = 0; r < 4; ++r) acc[r] = T[(16 * mi + (lane >> 4) + 4 * r) * ld + 16 * ni + (lane & 15)];
 }
-__device__ __forceinline__ void half_store_acc(double* __restrict__ T, int lane, int mi, const v4d acc[2]) {
+template <typename Ptr>
+__device__ __forceinline__ void quad_store(Ptr T, int ld, int lane, int mi, int ni, const v4d& acc) {
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T[(16 * mi + (lane >> 4) + 4 * r) * kTile + 16 * ni + (lane & 15)] = acc[ni][r];
+  for (int r = 0; r < 4; ++r) T[(16 * mi + (lane >> 4) + 4 * r) * ld + 16 * ni + (lane & 15)] = acc[r];
 }
-__device__ __forceinline__ void half_syrk_sub(const double* __restrict__ At, const double* __restrict__ Bt, int lane, int mi,
-                                              v4d acc[2]) {
-  const int row = lane & 15, kg = lane >> 4;
-  double a[8], b[2][8];
-  {
-    const double2* pa = reinterpret_cast<const double2*>(At + (16 * mi + row) * kTile + 8 * kg);
+// operands of a quadrant product over k = 0..31: lane l takes row 16 b + (l & 15), columns 8 (l >> 4) .. + 7 of a row-major
+// tile (the k index is permuted identically for both operands, which leaves the sum unchanged: 64 contiguous bytes per lane)
+__device__ __forceinline__ void quad_operand(const double* __restrict__ T, int lane, int b, double (&o)[8]) {
+  const double2* p = reinterpret_cast<const double2*>(T + (16 * b + (lane & 15)) * kTile + 8 * (lane >> 4));
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { const double2 x = pa[s]; a[2 * s] = -x.x; a[2 * s + 1] = -x.y; }
-  }
+  for (int s = 0; s < 4; ++s) { const double2 x = p[s]; o[2 * s] = x.x; o[2 * s + 1] = x.y; }
+}
+// acc -= A[16 mi .., :] B[16 ni .., :]^T
+__device__ __forceinline__ void quad_gemm_sub(const double (&a)[8], const double (&b)[8], v4d& acc) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const double2* pb = reinterpret_cast<const double2*>(Bt + (16 * h + row) * kTile + 8 * kg);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { const double2 y = pb[s]; b[h][2 * s] = y.x; b[h][2 * s + 1] = y.y; }
-  }
-#pragma unroll
-  for (int s = 0; s < 8; ++s)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[ni][s], acc[ni], 0, 0, 0);
+  for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], b[s], acc, 0, 0, 0);
 }
 
 // ---- trailing update of an outer panel: 64x64 output block per workgroup ---------------------------
@@ -382,6 +326,14 @@ __global__ __launch_bounds__(256) void k_big_update(double* A, int nt, int j, in
 
 int g_dbg_flags = 0;
 extern "C" void mpsfm_debug_set(int f) { g_dbg_flags = f; }
+// Phase timeline of the factorisation (diagnostics, scripts/dbg_chol_trace.py): when a buffer is registered, the
+// workgroup that owns the diagonal tile of every step stores wall_clock64() (100 MHz) at its phase boundaries,
+// 8 stamps per wave and step.
+__device__ long long* g_chol_trace = nullptr;
+extern "C" int mpsfm_debug_set_chol_trace(long long* dev_buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_trace), &dev_buf, sizeof(dev_buf));
+}
+#define MPSFM_STAMP(k) do { if (trace_on && lane == 0) tr[(k)] = wall_clock64(); } while (0)
 
 // One step of the right-looking factorisation, two waves per tile.  j = -1: factor tile column 0 only.
 //   trailing tile (tk > j+1):  A[ti][tk] -= L[ti][j] L[tk][j]^T, one 16-row half per wave.
@@ -394,7 +346,7 @@ extern "C" void mpsfm_debug_set(int f) { g_dbg_flags = f; }
 //   kStepNoOwnUpdate  the panel column j+1 has already received column j (first step of an outer panel),
 //   kStepBig          no factorisation: every tile (ti, tk), j < tk <= tk_max, gets columns c0..j at once
 //                     (one load and one store of the tile for a rank-32*(j-c0+1) update).
-constexpr int kStepNoOwnUpdate = 1, kStepBig = 2;
+constexpr int kStepNoOwnUpdate = 1, kStepBig = 2, kStepTri = 4;
 // Inverse propagation (plain path only, Pinv != NULL).  The back substitution y = L^-T z is a chain of nt dependent
 // tile solves — ten launches of ~10 us at nt = 38.  Instead the steps also build, in the shadow of their
 // latency-bound panel factorisation, the accumulators  P(i,k) = sum_{j=k}^{i-1} L(i,j) X(j,k)  of the inverse
@@ -408,160 +360,176 @@ constexpr int kStepNoOwnUpdate = 1, kStepBig = 2;
 #define MPSFM_INV_ROWS 2
 #endif
 constexpr int kInvRows = MPSFM_INV_ROWS;  // rows i handled by one inverse-role workgroup (X(j,k) is formed once for all of them)
+constexpr int kStepThreads = 256;         // four waves: one 16 x 16 quadrant of a tile each
 __device__ __forceinline__ void inv_role(const double* A, const double* LinvT, double* Pinv, int nt, int j, int i0, int i1, int k,
-                                         double (*s_A)[kTile + 1], double (*s_B)[kTile + 1], double* s_C, double (*s_M)[kTile + 1]) {
+                                         double (*s_B)[kTile + 1], double* s_C) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = wave & 1, ni = wave >> 1;
+  const int m16 = lane & 15, kg = lane >> 4;
   const double* Li = LinvT + (size_t)j * kTileElems;               // L(j,j)^-T, row-major
   const double* Pjk = Pinv + lt_tile(j, k) * kTileElems;           // only read when k < j
-  // the first row's accumulator and A operand are requested now: their latency runs under the formation of T
-  const int m16p = lane & 15, kgp = lane >> 4;
-  v4d acc0[2];
-  double a0[8];
-  {
-    half_load_acc(Pinv + lt_tile(i0, k) * kTileElems, lane, wave, acc0);
-    const double* arow = A + lt_tile(i0, j) * kTileElems + (16 * wave + m16p) * kTile + kgp;
+  // accumulators and A operands of every row of this workgroup are requested now: their latency runs under the
+  // formation of T.  Lane (m, q) reads L(i,j)[16 mi + m][4 s + kg], s = 0..7.
+  v4d acc[kInvRows];
+  double aop[kInvRows][8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) a0[s] = arow[4 * s];
+  for (int r = 0; r < kInvRows; ++r) {
+    const int i = min(i0 + r, i1 - 1);
+    quad_load(Pinv + lt_tile(i, k) * kTileElems, kTile, lane, mi, ni, acc[r]);
+    const double* arow = A + lt_tile(i, j) * kTileElems + (16 * mi + m16) * kTile + kg;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) aop[r][s] = arow[4 * s];
   }
-  for (int e = tid; e < kTileElems; e += 128) {
+  for (int e = tid; e < kTileElems; e += kStepThreads) {
     const int r = e >> 5, c = e & 31;
     s_B[r][c] = Li[e];
     s_C[e] = (k < j) ? Pjk[e] : 0.0;
   }
   __syncthreads();
-  const int m16 = lane & 15, kg = lane >> 4;
   // T = X(j,k): k < j: -(L(j,j)^-1 P(j,k)),  T[m][n] = -sum_q LinvT[q][m] Pjk[q][n];  k == j: L(j,j)^-1, T[m][n] = LinvT[n][m]
+  v4d t = {0, 0, 0, 0};
   if (k < j) {
-    v4d t[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const double a = -s_B[4 * s + kg][16 * wave + m16];
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) t[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, s_C[(4 * s + kg) * kTile + 16 * ni + m16], t[ni], 0, 0, 0);
-    }
-    __syncthreads();  // T overwrites L(j,j)^-T in LDS once both waves have consumed it
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_M[16 * wave + kg + 4 * r][16 * ni + m16] = t[ni][r];
-  } else {
-    double tr[kTileElems / 128];
-#pragma unroll
-    for (int u = 0; u < kTileElems / 128; ++u) { const int e = tid + 128 * u; tr[u] = s_B[e & 31][e >> 5]; }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kTileElems / 128; ++u) { const int e = tid + 128 * u; s_M[e >> 5][e & 31] = tr[u]; }
-  }
-  __syncthreads();
-  // P(i,k) += L(i,j) T for the rows of this workgroup; the B operand (T) stays in registers
-  double bT[8][2];
-#pragma unroll
-  for (int s = 0; s < 8; ++s)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) bT[s][ni] = s_M[4 * s + kg][16 * ni + m16];
-  for (int i = i0; i < i1; ++i) {
-    double* Pik = Pinv + lt_tile(i, k) * kTileElems;
-    v4d acc[2];
-    double a[8];
-    if (i == i0) {
-      acc[0] = acc0[0]; acc[1] = acc0[1];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) a[s] = a0[s];
-    } else {
-      half_load_acc(Pik, lane, wave, acc);
-      // A operand straight from the tile in memory: lane (m, q) reads L(i,j)[16 wave + m][4 s + kg]
-      const double* arow = A + lt_tile(i, j) * kTileElems + (16 * wave + m16) * kTile + kg;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) a[s] = arow[4 * s];
-    }
 #pragma unroll
     for (int s = 0; s < 8; ++s)
+      t = __builtin_amdgcn_mfma_f64_16x16x4f64(-s_B[4 * s + kg][16 * mi + m16], s_C[(4 * s + kg) * kTile + 16 * ni + m16], t, 0, 0, 0);
+  } else {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bT[s][ni], acc[ni], 0, 0, 0);
-    half_store_acc(Pik, lane, wave, acc);
+    for (int r = 0; r < 4; ++r) t[r] = s_B[16 * ni + m16][16 * mi + kg + 4 * r];
+  }
+  __syncthreads();  // T overwrites L(j,j)^-T in LDS once every wave has consumed it
+  quad_store(&s_B[0][0], kTile + 1, lane, mi, ni, t);
+  __syncthreads();
+  // P(i,k) += L(i,j) T for the rows of this workgroup; the B operand (T) stays in registers
+  double bT[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bT[s] = s_B[4 * s + kg][16 * ni + m16];
+#pragma unroll
+  for (int r = 0; r < kInvRows; ++r) {
+    if (i0 + r >= i1) break;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[r][s], bT[s], acc[r], 0, 0, 0);
+    quad_store(Pinv + lt_tile(i0 + r, k) * kTileElems, kTile, lane, mi, ni, acc[r]);
   }
 }
 
-__global__ __launch_bounds__(128) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg, int c0, int tk_max,
-                                                   int mode, double* Pinv, int cols) {
+__global__ __launch_bounds__(kStepThreads) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg, int c0, int tk_max,
+                                                            int mode, double* Pinv, int cols) {
   __shared__ double s_T[kTile][kTile + 1];
   __shared__ double s_X[kTile][kTile + 1];
-  __shared__ double s_Lt[kTile * kTile];
-  __shared__ double s_inv[kTile];
-  __shared__ double s_col[2][kTile];
-  __shared__ int s_ready;  // columns of L published by the factorising wave
+  __shared__ __attribute__((aligned(16))) double s_Lt[kTile * kTile];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (Pinv && (int)blockIdx.y >= cols) {
-    const int nrows = nt - 1 - j;  // i in (j, nt-1]
+  const int mi = wave & 1, ni = wave >> 1;  // this wave's quadrant
+  if (dbg & 16) return;  // ablation: the launch chain alone
+  int tk, ti;
+  if (mode & kStepTri) {
+    // plain step on a 1-D grid without idle workgroups: [panel tiles | trailing tiles | inverse roles]
+    const int npanel = nt - j;                 // ti = j+1 .. nt
+    const int m = nt - j - 2;                  // trailing tile columns j+2 .. nt-1; rows tk .. nt
+    const int ntrail = m > 0 ? m * (m + 3) / 2 : 0;
+    // order of dispatch = order of need: the panel column (the critical path), then the inverse roles (the longest
+    // workgroups), then the trailing tiles
+    const int nrows = nt - 1 - j;  // role rows i in (j, nt-1]
     const int ngrp = (nrows + kInvRows - 1) / kInvRows;
-    const int role = ((int)blockIdx.y - cols) * (int)gridDim.x + (int)blockIdx.x;
-    if (j < 0 || nrows <= 0 || role >= ngrp * (j + 1) || (dbg & 8)) return;  // dbg 8: dispatch the roles, do nothing
-    const int i0 = j + 1 + (role % ngrp) * kInvRows;
-    inv_role(A, LinvT, Pinv, nt, j, i0, min(i0 + kInvRows, nt), role / ngrp, s_T, s_X, s_Lt, s_X);
-    return;
+    const int nroles = (Pinv && j >= 0 && nrows > 0) ? ngrp * (j + 1) : 0;
+    int q = blockIdx.x;
+    if (q < npanel) {
+      tk = j + 1; ti = j + 1 + q;
+    } else if (q < npanel + nroles) {
+      const int role = q - npanel;
+      if (dbg & 8) return;  // dbg 8: dispatch the roles, do nothing
+      const int i0 = j + 1 + (role % ngrp) * kInvRows;
+      inv_role(A, LinvT, Pinv, nt, j, i0, min(i0 + kInvRows, nt), role / ngrp, s_T, s_Lt);
+      return;
+    } else {
+      q -= npanel + nroles;
+      if (q >= ntrail) return;
+      const int tri = m * (m + 1) / 2;
+      int r, c;
+      if (q >= tri) { r = m; c = q - tri; }    // the right-hand-side tile row
+      else {
+        r = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > q) --r;
+        while ((r + 1) * (r + 2) / 2 <= q) ++r;
+        c = q - r * (r + 1) / 2;
+      }
+      tk = j + 2 + c; ti = j + 2 + r;
+    }
+  } else {
+    tk = j + 1 + blockIdx.y;
+    ti = j + 1 + blockIdx.x;
+    if (ti < tk || tk >= nt || ti > nt || tk > tk_max) return;
   }
-  const int tk = j + 1 + blockIdx.y;
-  const int ti = j + 1 + blockIdx.x;
-  if (ti < tk || tk >= nt || ti > nt || tk > tk_max) return;
   double* C = A + lt_tile(ti, tk) * kTileElems;
   if (tk != j + 1 || (mode & kStepBig)) {
-    v4d acc[2];
-    half_load_acc(C, lane, wave, acc);
+    // trailing tile: A[ti][tk] -= sum_c L[ti][c] L[tk][c]^T, one quadrant per wave
+    v4d acc;
+    quad_load(C, kTile, lane, mi, ni, acc);
     if (!(dbg & 4))
-      for (int c = c0; c <= j; ++c) half_syrk_sub(A + lt_tile(ti, c) * kTileElems, A + lt_tile(tk, c) * kTileElems, lane, wave, acc);
-    half_store_acc(C, lane, wave, acc);
+      for (int c = c0; c <= j; ++c) {
+        double a[8], b[8];
+        quad_operand(A + lt_tile(ti, c) * kTileElems, lane, mi, a);
+        quad_operand(A + lt_tile(tk, c) * kTileElems, lane, ni, b);
+        quad_gemm_sub(a, b, acc);
+      }
+    quad_store(C, kTile, lane, mi, ni, acc);
     return;
   }
   const bool own_update = (j >= 0) && !(mode & kStepNoOwnUpdate) && !(dbg & 4);
   // ---- panel column j+1 -------------------------------------------------------------------
-
   const int row = lane & 31;
   const bool diag = (ti == tk);
-  if (threadIdx.x == 0) s_ready = 0;
-  if (wave == 0) {
-    // updated diagonal tile -> s_T
-    v4d dacc[2][2];
-    const double* Dg = A + lt_tile(tk, tk) * kTileElems;
-    tile_load_acc(Dg, lane, dacc);
+  long long* tr = g_chol_trace ? g_chol_trace + ((size_t)(j + 1) * 2) * 8 : nullptr;
+  const bool trace_on = diag && tr != nullptr && wave == 0;
+  MPSFM_STAMP(0);
+  {
+    // every wave: its quadrant of the updated diagonal tile -> s_T and of the workgroup's own updated tile -> s_X
+    v4d dacc, xacc;
+    quad_load(A + lt_tile(tk, tk) * kTileElems, kTile, lane, mi, ni, dacc);
+    if (!diag) quad_load(C, kTile, lane, mi, ni, xacc);
     if (own_update) {
       const double* Lk = A + lt_tile(tk, j) * kTileElems;
-      tile_syrk_sub(Lk, Lk, lane, dacc);
+      double am[8], bn[8];
+      quad_operand(Lk, lane, mi, am);
+      quad_operand(Lk, lane, ni, bn);
+      quad_gemm_sub(am, bn, dacc);
+      if (!diag) {
+        quad_operand(A + lt_tile(ti, j) * kTileElems, lane, mi, am);
+        quad_gemm_sub(am, bn, xacc);
+      }
     }
-    tile_store_acc(&s_T[0][0], kTile + 1, lane, dacc);
-  } else if (!diag) {
-    // this workgroup's own updated tile -> s_X
-    v4d acc[2][2];
-    tile_load_acc(C, lane, acc);
-    if (own_update) tile_syrk_sub(A + lt_tile(ti, j) * kTileElems, A + lt_tile(tk, j) * kTileElems, lane, acc);
-    tile_store_acc(&s_X[0][0], kTile + 1, lane, acc);
+    quad_store(&s_T[0][0], kTile + 1, lane, mi, ni, dacc);
+    if (diag) {  // identity: x L^-T = row of L^-T
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xacc[r] = (16 * mi + (lane >> 4) + 4 * r == 16 * ni + (lane & 15)) ? 1.0 : 0.0;
+    }
+    quad_store(&s_X[0][0], kTile + 1, lane, mi, ni, xacc);
   }
+  MPSFM_STAMP(1);
   __syncthreads();
-  double x[kTile];
-  if (wave == 0) {
-    bool ok = true;
-    if (!(dbg & 1)) ok = potrf_tile(s_T, lane, s_inv, s_col, s_Lt, &s_ready);
-    else if (lane == 0) __hip_atomic_store(&s_ready, kTile, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    // The factored diagonal tile is NOT written back over A(tk,tk): every workgroup of this panel column
-    // loads A(tk,tk) at its start, and one that is scheduled late (a busy GPU) would otherwise find L there
-    // instead of the matrix.  Nothing reads L(tk,tk) from memory afterwards — the back substitution uses the
-    // stored L^-T of the diagonal tiles.
-    if (diag && !ok && lane == 0) atomicExch(fail, 1);
-  } else {
-    if (diag) {
+  MPSFM_STAMP(2);
+  if (wave != 0) return;
+  // stacked factorisation by wave 0: lanes 0..31 rows of D, lanes 32..63 rows of X (identity for the diagonal workgroup)
+  double a[kTile];
+  {
+    const double* src = (lane < kTile) ? &s_T[row][0] : &s_X[row][0];
 #pragma unroll
-      for (int c = 0; c < kTile; ++c) x[c] = (c == row) ? 1.0 : 0.0;  // identity: x L^-T = row of L^-T
-    } else {
-#pragma unroll
-      for (int c = 0; c < kTile; ++c) x[c] = s_X[row][c];
-    }
-    if (!(dbg & 2)) trsm_row(x, s_Lt, s_inv, &s_ready);
-    if (lane < kTile) {
-      double2* dst = diag ? reinterpret_cast<double2*>(LinvT + (size_t)tk * kTileElems + lane * kTile)
-                          : reinterpret_cast<double2*>(C + lane * kTile);
-#pragma unroll
-      for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(x[c], x[c + 1]);
-    }
+    for (int c = 0; c < kTile; ++c) a[c] = src[c];
   }
+  bool ok = true;
+  if (!(dbg & 1)) stacked_panel<0>(a, lane, s_Lt, ok);
+  MPSFM_STAMP(3);
+  // The factored diagonal tile is NOT written back over A(tk,tk): every workgroup of this panel column loads
+  // A(tk,tk) at its start, and one that is scheduled late (a busy GPU) would otherwise find L there instead of the
+  // matrix.  Nothing reads L(tk,tk) from memory afterwards — the back substitution uses the stored L^-T of the
+  // diagonal tiles.
+  if (diag && !ok && lane == 0) atomicExch(fail, 1);
+  if (lane >= kTile) {
+    double2* dst = diag ? reinterpret_cast<double2*>(LinvT + (size_t)tk * kTileElems + row * kTile)
+                        : reinterpret_cast<double2*>(C + row * kTile);
+#pragma unroll
+    for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(a[c], a[c + 1]);
+  }
+  MPSFM_STAMP(4);
 }
 
 // ---- back substitution  y = L^-T z  in groups of kBsG tile rows --------------------------------
@@ -753,18 +721,26 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   for (int p0 = 0; p0 < nt; p0 += NB, ++npanel) {
     const int pend = (p0 + NB - 1 < nt - 1) ? p0 + NB - 1 : nt - 1;
     // factor column p0 (its tiles already hold every earlier column); ti in [p0, nt]
-    hipLaunchKernelGGL(k_chol_step, dim3(nt - p0 + 1, 1), dim3(128), 0, s, A, LinvT, nt, p0 - 1, fail, g_dbg_flags, p0 - 1, p0,
+    hipLaunchKernelGGL(k_chol_step, dim3(nt - p0 + 1, 1), dim3(kStepThreads), 0, s, A, LinvT, nt, p0 - 1, fail, g_dbg_flags, p0 - 1, p0,
                        kStepNoOwnUpdate, (double*)nullptr, 1);
     for (int j = p0; j <= pend - 1; ++j) {  // apply column j to columns (j, pend], factor column j+1; ti in [j+1, nt]
       const int rows = nt - j, cols = pend - j;
-      // inverse roles of launch j: (nt-1-j) rows x (j+1) columns, appended behind the tile grid
-      const int extra = Pinv ? (((nt - 1 - j + kInvRows - 1) / kInvRows) * (j + 1) + rows - 1) / rows : 0;
-      hipLaunchKernelGGL(k_chol_step, dim3(rows, cols + extra), dim3(128), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0, Pinv, cols);
+      if (pend >= nt - 1) {
+        // plain step: every trailing column is touched; 1-D grid [panel | trailing triangle | inverse roles]
+        const int m = nt - j - 2;
+        const int ntrail = m > 0 ? m * (m + 3) / 2 : 0;
+        const int nroles = Pinv ? ((nt - 1 - j + kInvRows - 1) / kInvRows) * (j + 1) : 0;
+        hipLaunchKernelGGL(k_chol_step, dim3(rows + ntrail + nroles), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend,
+                           kStepTri, Pinv, cols);
+      } else {
+        hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0,
+                           (double*)nullptr, cols);
+      }
     }
     if (pend >= nt - 1) break;
     // columns (pend, nt-1] receive the panel p0..pend; ti in [pend+1, nt]
     if (!big_kernel) {
-      hipLaunchKernelGGL(k_chol_step, dim3(nt - pend, nt - 1 - pend), dim3(128), 0, s, A, LinvT, nt, pend, fail, g_dbg_flags, p0, nt - 1,
+      hipLaunchKernelGGL(k_chol_step, dim3(nt - pend, nt - 1 - pend), dim3(kStepThreads), 0, s, A, LinvT, nt, pend, fail, g_dbg_flags, p0, nt - 1,
                          kStepBig, (double*)nullptr, nt - 1 - pend);
     } else if (!overlap) {
       launch_big(A, nt, pend, p0, pend + 1, nt - 1, s);
