@@ -228,6 +228,37 @@ int mpsfm_filter_tracks(const mpsfm_tracks* tracks, const double* xyz /* [n_trac
                         int32_t device, double* max_tri_angle /* [n_tracks] */,
                         double* el_sq_err /* [n_el] */, uint8_t* el_front /* [n_el] */);
 
+/* -- row f3: depth-block selection of Optimizer.__build_problem for a whole bundle in one launch
+ *    (mpsfm/sfm/mapper/bundle_adjustment.py:124-161) and the whitened log-depth errors of
+ *    update_truncation_multiplier (:295-333).  Per keypoint that has a 3-D point: bilinear samples of the validity
+ *    mask and the depth map (PriorUtils._data_at_kps, image/mixins/priorutils.py:49-62: grid_sample, zero padding,
+ *    align_corners=True, keypoints scaled by camera.sx / sy), the camera-frame depth of the point
+ *    (points3D_utils.py:9-25), the masks and the loss weights.
+ *    flags bit 0: valid_at_kps (sample == 1), bit 1: depth > 0, bit 2: 1/f < depth/depth3d < f,
+ *          bit 3: |log d.clip - log z.clip| / sqrt(var) < 3 (gross_outliers test, :145-147)
+ *    magnitude = d^2 / clip(var, 1e-6) (:161), param = multiplier * sqrt(var) / d (:160),
+ *    whitened  = (log d - log z) / clip(sqrt(var) / d, 1e-6) (:323-329). ------------------------------------- */
+typedef struct mpsfm_depth_gather {
+  int32_t n_images;
+  const int32_t* map_h; const int32_t* map_w;    /* [n_images] */
+  const double* const* depth_map;                 /* [n_images] -> H*W, depth.data ("update") or depth.data_prior */
+  const uint8_t* const* valid_map;                /* [n_images] -> H*W, depth.valid */
+  const double* sx; const double* sy;             /* [n_images] camera.sx, camera.sy */
+  const double* cam_quat_xyzw; const double* cam_t; /* [n_images][4], [n_images][3] */
+  int64_t n_obs;                                  /* keypoints with a 3-D point, all images */
+  const int32_t* obs_img;                         /* [n_obs] image index */
+  const double* obs_xy;                           /* [n_obs][2] keypoint, original image scale */
+  const double* obs_var;                          /* [n_obs] depth.uncertainty_update[point2D_idx] */
+  const int32_t* obs_pt;                          /* [n_obs] index into pts */
+  int32_t n_pts;
+  const double* pts;                              /* [n_pts][3] */
+  int32_t scale_filter; double scale_filter_factor; int32_t gross_outliers;
+  double multiplier;                              /* param_multiplier * truncation_multiplier * rob_std (:109,159) */
+} mpsfm_depth_gather;
+
+int mpsfm_depth_blocks(const mpsfm_depth_gather* g, int32_t device, uint8_t* flags /* [n_obs] */, double* depth,
+                       double* depth3d, double* magnitude, double* param, double* whitened /* each [n_obs] */);
+
 /* -- depth-from-normals integration: replaces the per-image solve of Image.integrate()
  *    (mpsfm/sfm/scene/image/integration.py:133-137 -> _integrate :383-520): IRLS over a 5-point SPD
  *    system on the H*W log-depths with Jacobi-preconditioned CG (scipy/cupy `cg` semantics), bilateral

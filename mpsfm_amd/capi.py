@@ -23,7 +23,7 @@ EXPORTS = [
     "mpsfm_ba_sweep_once", "mpsfm_ba_get_reduced_system", "mpsfm_ba_reduced_dim",
     "mpsfm_ba_get_dense_solution", "mpsfm_ba_dense_solve_once", "mpsfm_point_covs",
     "mpsfm_triangulate_tracks", "mpsfm_filter_tracks", "mpsfm_integrate_depth", "mpsfm_integrate_depth_batch",
-    "mpsfm_integration_variances",
+    "mpsfm_integration_variances", "mpsfm_depth_blocks",
 ]
 
 _lib = None
@@ -208,6 +208,50 @@ def filter_tracks(tr: Tracks, xyz: np.ndarray, device: int = 0):
     ct = tr.c_tracks()
     _check(lib().mpsfm_filter_tracks(C.byref(ct), xyz.ctypes.data, device, ang.ctypes.data, err.ctypes.data, front.ctypes.data))
     return ang, err, front.astype(bool)
+
+
+class CDepthGather(C.Structure):
+    _fields_ = [
+        ("n_images", C.c_int32), ("map_h", C.c_void_p), ("map_w", C.c_void_p), ("depth_map", C.c_void_p), ("valid_map", C.c_void_p),
+        ("sx", C.c_void_p), ("sy", C.c_void_p), ("cam_quat_xyzw", C.c_void_p), ("cam_t", C.c_void_p),
+        ("n_obs", C.c_int64), ("obs_img", C.c_void_p), ("obs_xy", C.c_void_p), ("obs_var", C.c_void_p), ("obs_pt", C.c_void_p),
+        ("n_pts", C.c_int32), ("pts", C.c_void_p),
+        ("scale_filter", C.c_int32), ("scale_filter_factor", C.c_double), ("gross_outliers", C.c_int32), ("multiplier", C.c_double),
+    ]
+
+
+def depth_blocks(depth_maps, valid_maps, sx, sy, cam_quat, cam_t, obs_img, obs_xy, obs_var, obs_pt, pts, scale_filter_factor=1.5,
+                 multiplier=2.0, device=0):
+    """mpsfm_depth_blocks: the depth-block selection of a whole bundle in one launch.  `depth_maps` / `valid_maps`: one
+    [H,W] array per image.  Returns dict(flags uint8 [n], depth, depth3d, magnitude, param, whitened float64 [n])."""
+    n_img = len(depth_maps)
+    dm = [np.ascontiguousarray(m, np.float64) for m in depth_maps]
+    vm = [np.ascontiguousarray(m, np.uint8) for m in valid_maps]
+    hh = np.array([m.shape[0] for m in dm], np.int32)
+    ww = np.array([m.shape[1] for m in dm], np.int32)
+    f64 = lambda a, shape=None: np.ascontiguousarray(a, np.float64).reshape(shape) if shape else np.ascontiguousarray(a, np.float64)  # noqa: E731
+    sx, sy, cam_quat, cam_t = f64(sx), f64(sy), f64(cam_quat, (-1, 4)), f64(cam_t, (-1, 3))
+    obs_img, obs_pt = np.ascontiguousarray(obs_img, np.int32), np.ascontiguousarray(obs_pt, np.int32)
+    obs_xy, obs_var, pts = f64(obs_xy, (-1, 2)), f64(obs_var), f64(pts, (-1, 3))
+    n = len(obs_img)
+    G = CDepthGather()
+    G.n_images = n_img
+    G.map_h, G.map_w = hh.ctypes.data, ww.ctypes.data
+    dptr = (C.c_void_p * max(n_img, 1))(*[m.ctypes.data for m in dm])
+    vptr = (C.c_void_p * max(n_img, 1))(*[m.ctypes.data for m in vm])
+    G.depth_map, G.valid_map = C.addressof(dptr), C.addressof(vptr)
+    G.sx, G.sy, G.cam_quat_xyzw, G.cam_t = sx.ctypes.data, sy.ctypes.data, cam_quat.ctypes.data, cam_t.ctypes.data
+    G.n_obs = n
+    G.obs_img, G.obs_xy, G.obs_var, G.obs_pt = obs_img.ctypes.data, obs_xy.ctypes.data, obs_var.ctypes.data, obs_pt.ctypes.data
+    G.n_pts, G.pts = len(pts), pts.ctypes.data
+    G.scale_filter, G.scale_filter_factor, G.gross_outliers, G.multiplier = 1, float(scale_filter_factor), 0, float(multiplier)
+    out = {k: np.zeros(n) for k in ("depth", "depth3d", "magnitude", "param", "whitened")}
+    out["flags"] = np.zeros(n, np.uint8)
+    L = lib()
+    L.mpsfm_depth_blocks.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 6
+    _check(L.mpsfm_depth_blocks(C.byref(G), device, out["flags"].ctypes.data, out["depth"].ctypes.data, out["depth3d"].ctypes.data,
+                                out["magnitude"].ctypes.data, out["param"].ctypes.data, out["whitened"].ctypes.data))
+    return out
 
 
 INT_DEFAULT_CONF = dict(

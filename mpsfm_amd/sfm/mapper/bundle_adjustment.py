@@ -20,6 +20,7 @@ import numpy as np
 
 from ...baseclass import BaseClass
 from ...problem import LOSS_BY_NAME, LOSS_CAUCHY, LOSS_SOFT_L1, LOSS_TRIVIAL, BAProblem
+from ..scene.prior_gather import F_GROSS, F_POSITIVE, F_SCALE, F_VALID, gather_bundle
 from ..scene.priorutils import fit_robust_gaussian_mad
 
 _COLMAP_LOSS = {"TRIVIAL": LOSS_TRIVIAL, "SOFT_L1": LOSS_SOFT_L1, "CAUCHY": LOSS_CAUCHY}
@@ -55,6 +56,31 @@ class HipBackend:
         from ... import capi
 
         return capi.point_covs(prob, self.device)
+
+    def depth_blocks(self, **kw) -> dict:
+        from ... import capi
+
+        return capi.depth_blocks(device=self.device, **kw)
+
+
+class _SortedIndex:
+    """id -> position in a sorted id array with the mapping interface the callers use (`in`, [])."""
+
+    def __init__(self, ids):
+        self.ids = ids
+
+    def _pos(self, pid):
+        i = int(np.searchsorted(self.ids, pid))
+        return i if i < len(self.ids) and self.ids[i] == pid else -1
+
+    def __contains__(self, pid):
+        return self._pos(pid) >= 0
+
+    def __getitem__(self, pid):
+        i = self._pos(pid)
+        if i < 0:
+            raise KeyError(pid)
+        return i
 
 
 @dataclass
@@ -133,22 +159,32 @@ class Optimizer(BaseClass):
             xy_l.append(np.asarray(image.keypoint_coordinates(p2d), dtype=np.float64).reshape(-1, 2))
         if pids_l:
             uniq, inv, counts = np.unique(np.concatenate(pids_l), return_inverse=True, return_counts=True)
-            obs_cam, obs_pt, obs_xy = list(cams_l), [inv.astype(np.int32)], list(xy_l)
-            obs_cam = [np.concatenate(obs_cam)]
+            obs_cam, obs_pt, obs_xy = [np.concatenate(cams_l)], [inv.astype(np.int32)], list(xy_l)
         else:
             uniq, counts = np.zeros(0, np.uint64), np.zeros(0, np.int64)
             obs_cam, obs_pt, obs_xy = [], [], []
-        point_ids = [int(v) for v in uniq]
-        pt_of = dict(zip(point_ids, range(len(point_ids))))
-        num_obs = dict(zip(point_ids, (int(c) for c in counts)))
-        extra_cam, extra_pt, extra_xy = [], [], []
-        for pid in variable_points:
+        self._sorted_point_ids = uniq  # bundle-image points, sorted: index = position (depth blocks look ids up here)
+        point_ids = uniq.astype(np.int64)
+        num_obs = counts.astype(np.int64)
+        # explicitly variable points whose track leaves the bundle: their outside observations come along, constant poses
+        vp = np.fromiter((int(p) for p in variable_points), np.int64, len(variable_points)) if len(variable_points) else np.zeros(0, np.int64)
+        if len(vp):
+            pos = np.searchsorted(point_ids, vp)
+            inside = (pos < len(point_ids)) & (point_ids[np.minimum(pos, max(len(point_ids) - 1, 0))] == vp) if len(point_ids) else np.zeros(len(vp), bool)
+            n_in = np.where(inside, num_obs[np.minimum(pos, max(len(point_ids) - 1, 0))] if len(point_ids) else 0, 0)
+            todo = vp[self._track_lengths(vp) != n_in]
+        else:
+            todo = vp
+        extra_ids, extra_cam, extra_pt, extra_xy = [], [], [], []
+        pt_of = None
+        for pid in todo:
+            pid = int(pid)
+            if pt_of is None:
+                pt_of = {int(v): i for i, v in enumerate(point_ids)}
             point = rec.points3D[pid]
-            if num_obs.get(pid, 0) == point.track.length():
-                continue
             if pid not in pt_of:
-                pt_of[pid] = len(point_ids)
-                point_ids.append(pid)
+                pt_of[pid] = len(point_ids) + len(extra_ids)
+                extra_ids.append(pid)
             for el in point.track.elements:
                 if el.image_id in in_config:
                     continue
@@ -157,19 +193,23 @@ class Optimizer(BaseClass):
                     image_ids.append(el.image_id)
                 extra_cam.append(cam_of[el.image_id]); extra_pt.append(pt_of[pid])
                 extra_xy.append(np.asarray(rec.images[el.image_id].points2D[el.point2D_idx].xy, np.float64))
-                num_obs[pid] = num_obs.get(pid, 0) + 1
+        if extra_ids:
+            point_ids = np.concatenate([point_ids, np.array(extra_ids, np.int64)])
+            num_obs = np.concatenate([num_obs, np.zeros(len(extra_ids), np.int64)])
         if extra_cam:
+            np.add.at(num_obs, np.array(extra_pt, np.int64), 1)
             obs_cam.append(np.array(extra_cam, np.int32)); obs_pt.append(np.array(extra_pt, np.int32))
             obs_xy.append(np.array(extra_xy, np.float64).reshape(-1, 2))
         obs_cam = np.concatenate(obs_cam) if obs_cam else np.zeros(0, np.int32)
         obs_pt = np.concatenate(obs_pt) if obs_pt else np.zeros(0, np.int32)
         obs_xy = np.concatenate(obs_xy) if obs_xy else np.zeros((0, 2))
-        self._sorted_point_ids = uniq  # bundle-image points, sorted: index = position (depth blocks look ids up here)
         n_cfg = len(optim_ids)
         pose_const = np.ones(len(image_ids), np.uint8)
         for ii in range(n_cfg):
             pose_const[ii] = 1 if (fix_pose or ii == 0) else 0
-        pt_const = np.array([1 if rec.points3D[pid].track.length() > num_obs[pid] else 0 for pid in point_ids], np.uint8)
+        pt_const = (self._track_lengths(point_ids) > num_obs).astype(np.uint8)
+        if pt_of is None:
+            pt_of = _SortedIndex(point_ids)
         gauge = 1 if (not fix_pose and n_cfg > 1) else -1
         return image_ids, cam_of, point_ids, pt_of, obs_cam, obs_pt, obs_xy, pose_const, pt_const, gauge
 
@@ -193,43 +233,29 @@ class Optimizer(BaseClass):
         gross_outliers = conf.gross_outliers
         param_multiplier = param_multiplier * self.truncation_multiplier
 
-        dobs_cam, dobs_pt, dobs_d, dobs_m, dobs_a = [], [], [], [], []
-        for imid in optim_ids:
-            image = rec.images[imid]
-            if not image.depth.activated:
-                continue
-            p2Ds = np.asarray(image.get_observation_point2D_idxs(), dtype=np.int64)
-            if len(p2Ds) == 0:
-                continue
-            kps = np.asarray(image.keypoint_coordinates(p2Ds))
-            valid = image.depth.valid_at_kps(kps)
-            kps = kps[valid]
-            depths = image.depth.data_at_kps(kps) if depth_type == "update" else image.depth.data_prior_at_kps(kps)
-            p2Ds = p2Ds[valid]
-            p3Ds = np.asarray(image.point3D_ids(p2Ds), dtype=np.uint64)
-            if len(p3Ds) == 0:
-                continue
-            _, _, _, depth3d, _ = rec.project_image_3d_points(imid, p3Ds)
-            mask = depths > 0
+        # depth blocks of every activated bundle image (reference :124-176): the keypoints are gathered
+        # per image through the reference's accessors, the sampling / projection / masks / weights run in ONE launch
+        dobs_cam = dobs_pt = np.zeros(0, np.int32)
+        dobs_d = dobs_m = dobs_a = np.zeros(0)
+        g = gather_bundle(rec, optim_ids, depth_type)
+        if g is not None:
+            out = self.backend.depth_blocks(
+                depth_maps=g["depth_maps"], valid_maps=g["valid_maps"], sx=g["sx"], sy=g["sy"], cam_quat=g["cam_quat"], cam_t=g["cam_t"],
+                obs_img=g["obs_img"], obs_xy=g["obs_xy"], obs_var=g["obs_var"], obs_pt=g["obs_pt"], pts=self._coordinates(g["point_ids"]),
+                scale_filter_factor=scale_filter_factor, multiplier=param_multiplier * conf.rob_std)
+            f = out["flags"]
+            mask = ((f & F_VALID) != 0) & ((f & F_POSITIVE) != 0)
             if allow_scale_filter and conf.scale_filter:
-                div = depths / depth3d
-                mask = mask & (div < scale_filter_factor) & (div > (1 / scale_filter_factor))
-            uu = image.depth.uncertainty_update
-            variances = np.asarray(uu, np.float64)[p2Ds] if isinstance(uu, np.ndarray) else np.array([uu[int(i)] for i in p2Ds], np.float64)
-            if gross_outliers and image.depth.activated:
-                whitened = np.abs(np.log(depths).clip(1e-6, None) - np.log(depth3d).clip(1e-6, None)) / variances**0.5
-                mask = mask & (whitened < 3)
-            if np.sum(mask) == 0:
-                self.log("No valid points for depth regularizing", level=1)
-                continue
-            depths, variances, p3Ds = depths[mask], variances[mask], p3Ds[mask]
-            inv_uncert = 1 / variances.clip(1e-6, None)
-            m = param_multiplier * conf.rob_std
-            params = m * variances**0.5 / depths
-            magnitudes = depths**2 * inv_uncert
-            dobs_cam.append(np.full(len(p3Ds), cam_of[imid], np.int32))
-            dobs_pt.append(np.searchsorted(self._sorted_point_ids, p3Ds).astype(np.int32))
-            dobs_d.append(depths); dobs_m.append(magnitudes); dobs_a.append(params)
+                mask &= (f & F_SCALE) != 0
+            if gross_outliers:
+                mask &= (f & F_GROSS) != 0
+            for k, imid in enumerate(g["images"]):
+                if not mask[g["obs_img"] == k].any():
+                    self.log("No valid points for depth regularizing", level=1)
+            cam_idx = np.array([cam_of[i] for i in g["images"]], np.int32)
+            dobs_cam = cam_idx[g["obs_img"][mask]]
+            dobs_pt = np.searchsorted(self._sorted_point_ids, g["obs_pid"][mask]).astype(np.int32)
+            dobs_d, dobs_m, dobs_a = out["depth"][mask], out["magnitude"][mask], out["param"][mask]
 
         n_cams = len(image_ids)
         cam_ids = [rec.images[i].camera_id for i in image_ids]
@@ -238,18 +264,14 @@ class Optimizer(BaseClass):
         prob = BAProblem(
             cam_quat=np.array([rec.images[i].cam_from_world.rotation.quat for i in image_ids]).reshape(-1, 4),
             cam_t=np.array([rec.images[i].cam_from_world.translation for i in image_ids]).reshape(-1, 3),
-            pts=np.array([rec.points3D[p].xyz for p in point_ids]).reshape(-1, 3),
+            pts=self._coordinates(point_ids),
             cam_intr=intr, cam_intr_idx=np.array([uniq.index(c) for c in cam_ids], np.int32),
             pose_const=pose_const, pt_const=pt_const,
             obs_cam=np.array(obs_cam, np.int32), obs_pt=np.array(obs_pt, np.int32),
             obs_xy=np.array(obs_xy, np.float64).reshape(-1, 2), gauge_axis_cam=gauge if n_cams > 1 else -1,
             reproj_loss_type=_COLMAP_LOSS[str(conf.reproj_loss_name).upper()],
             reproj_loss_scale=conf.reproj_loss_scale * kp_std, reproj_loss_magnitude=1 / kp_std**2,
-            dobs_cam=np.concatenate(dobs_cam) if dobs_cam else np.zeros(0, np.int32),
-            dobs_pt=np.concatenate(dobs_pt) if dobs_pt else np.zeros(0, np.int32),
-            dobs_depth=np.concatenate(dobs_d) if dobs_d else np.zeros(0),
-            dobs_magnitude=np.concatenate(dobs_m) if dobs_m else np.zeros(0),
-            dobs_param=np.concatenate(dobs_a) if dobs_a else np.zeros(0),
+            dobs_cam=dobs_cam, dobs_pt=dobs_pt, dobs_depth=dobs_d, dobs_magnitude=dobs_m, dobs_param=dobs_a,
             depth_loss_type=depth_loss_type,
         )
         flat = FlatProblem(prob, image_ids, point_ids, shift_scale)
@@ -270,9 +292,13 @@ class Optimizer(BaseClass):
             pose = rec.images[imid].cam_from_world
             pose.rotation.quat[:] = prob.cam_quat[ci]
             pose.translation[:] = prob.cam_t[ci]
-        for pi, pid in enumerate(problem.point_ids):
-            if not prob.pt_const[pi]:
-                rec.points3D[pid].xyz[:] = prob.pts[pi]
+        var = np.flatnonzero(prob.pt_const == 0)
+        ids = np.asarray(problem.point_ids)[var]
+        if hasattr(rec, "set_point3D_coordinates"):  # bulk write when the scene offers one
+            rec.set_point3D_coordinates(ids, prob.pts[var])
+        else:
+            for pi, pid in zip(var, ids):
+                rec.points3D[int(pid)].xyz[:] = prob.pts[pi]
         self.log(
             f"LM iterations {summary['num_iterations']}, cost {summary['initial_cost']:.6e} -> {summary['final_cost']:.6e}, "
             f"{summary['termination']}", level=2)
@@ -302,7 +328,7 @@ class Optimizer(BaseClass):
         prob = BAProblem(
             cam_quat=np.array([rec.images[i].cam_from_world.rotation.quat for i in image_ids]).reshape(-1, 4),
             cam_t=np.array([rec.images[i].cam_from_world.translation for i in image_ids]).reshape(-1, 3),
-            pts=np.array([rec.points3D[p].xyz for p in point_ids]).reshape(-1, 3),
+            pts=self._coordinates(point_ids),
             cam_intr=np.array([pinhole_params(rec.rec.cameras[c]) for c in uniq]).reshape(-1, 4),
             cam_intr_idx=np.array([uniq.index(c) for c in cam_ids], np.int32), pose_const=pose_const, pt_const=pt_const,
             obs_cam=np.array(obs_cam, np.int32), obs_pt=np.array(obs_pt, np.int32),
@@ -310,9 +336,12 @@ class Optimizer(BaseClass):
             reproj_loss_scale=1.0, reproj_loss_magnitude=1 / kp_std**2,
         )
         covs = self.backend.point_covs(prob)
+        data = rec.point_covs.data
+        index = {int(v): i for i, v in enumerate(point_ids)}
         for p3Did in bundle["pts3D"]:
-            if p3Did in pt_of:
-                rec.point_covs.data[p3Did] = covs[pt_of[p3Did]]
+            i = index.get(p3Did)
+            if i is not None:
+                data[p3Did] = covs[i]
 
     # ------------------------------------------------------------------------------------------
     def _build_shiftscale_problem(self, bundle, allow_scale_filter=False, allow_metric_scale_filter=False):
@@ -354,30 +383,28 @@ class Optimizer(BaseClass):
         return {imid: (shift, np.exp(scale)) for imid, (shift, scale) in shift_scale.items()}, True
 
     def update_truncation_multiplier(self, imids):
-        """sigma of the whitened log-depth errors by MAD over the given images (reference :295-333)."""
-        rec = self.mpsfm_rec
-        D, D3d, stds = [], [], []
-        for imid in imids:
-            image = rec.images[imid]
-            p2Ds = np.asarray(image.get_observation_point2D_idxs(), dtype=np.int64)
-            if len(p2Ds) == 0:
-                continue
-            kps = np.asarray(image.keypoint_coordinates(p2Ds))
-            valid = image.depth.valid_at_kps(kps)
-            depths = image.depth.data_at_kps(kps[valid])
-            p2Ds = p2Ds[valid]
-            p3Ds = np.asarray(image.point3D_ids(p2Ds), dtype=np.uint64)
-            mask = depths > 0
-            if mask.sum() == 0:
-                continue
-            _, _, _, depth3d, _ = rec.project_image_3d_points(imid, p3Ds[mask])
-            uu = image.depth.uncertainty_update
-            D.append(depths[mask]); D3d.append(depth3d)
-            vv = np.asarray(uu, np.float64)[p2Ds[mask]] if isinstance(uu, np.ndarray) else np.array([uu[int(i)] for i in p2Ds[mask]])
-            stds.append(vv**0.5)
-        depths, depth3ds, dstds = np.concatenate(D), np.concatenate(D3d), np.concatenate(stds)
-        log_stds = np.clip(dstds / depths, 1e-6, None)
-        _, sigma = fit_robust_gaussian_mad((np.log(depths) - np.log(depth3ds)) / log_stds)
+        """sigma of the whitened log-depth errors by MAD over the given images (reference :295-333); the per-keypoint
+        sampling, projection and whitening run in the same launch as the depth-block selection."""
+        g = gather_bundle(self.mpsfm_rec, imids, "update")
+        out = self.backend.depth_blocks(
+            depth_maps=g["depth_maps"], valid_maps=g["valid_maps"], sx=g["sx"], sy=g["sy"], cam_quat=g["cam_quat"], cam_t=g["cam_t"],
+            obs_img=g["obs_img"], obs_xy=g["obs_xy"], obs_var=g["obs_var"], obs_pt=g["obs_pt"], pts=self._coordinates(g["point_ids"]),
+            scale_filter_factor=self.conf.scale_filter_factor, multiplier=1.0)
+        f = out["flags"]
+        sel = ((f & F_VALID) != 0) & ((f & F_POSITIVE) != 0)
+        _, sigma = fit_robust_gaussian_mad(out["whitened"][sel])
         self.truncation_multiplier = sigma
         if self.conf.min_truncation_mult is not None:
             self.truncation_multiplier = max(self.truncation_multiplier, self.conf.min_truncation_mult)
+
+    def _track_lengths(self, point_ids):
+        """track length of every given point: a bulk accessor when the scene has one, else the reference's per-point
+        point3D.track.length()"""
+        rec = self.mpsfm_rec
+        if hasattr(rec, "point3D_track_lengths"):
+            return np.asarray(rec.point3D_track_lengths(point_ids), np.int64)
+        return np.array([rec.points3D[int(p)].track.length() for p in point_ids], np.int64)
+
+    def _coordinates(self, point_ids):
+        """xyz of the given points: the reference's bulk accessor mpsfm_rec.point3D_coordinates (used at :233)."""
+        return np.asarray(self.mpsfm_rec.point3D_coordinates(point_ids), np.float64).reshape(-1, 3)

@@ -96,10 +96,60 @@ class Track:
 
 
 class NumpyPoint3D:
-    def __init__(self, xyz, track=None):
-        self.xyz = np.array(xyz, dtype=np.float64)
+    """A 3-D point whose coordinates live in the scene's columnar store (bulk reads / writes of many points are one
+    NumPy gather); ``xyz`` is a writable view of its row, like pycolmap's Point3D.xyz is a view of the C++ object."""
+
+    def __init__(self, xyz, track=None, store=None, row=-1):
+        self._store, self._row = store, row
+        if store is None:
+            self._own = np.array(xyz, dtype=np.float64)
+        else:
+            store.xyz[row] = xyz
         self.error = -1.0
         self.track = track if track is not None else Track()
+
+    @property
+    def xyz(self):
+        return self._own if self._store is None else self._store.xyz[self._row]
+
+    @xyz.setter
+    def xyz(self, value):
+        self.xyz[:] = value
+
+
+class _PointStore:
+    """Rows of xyz / track lengths indexed by point id through a lookup table (ids are small integers here)."""
+
+    def __init__(self, capacity=1 << 16):
+        self.xyz = np.zeros((capacity, 3))
+        self.tlen = np.zeros(capacity, np.int64)
+        self.row_of = np.full(capacity, -1, np.int64)  # id -> row
+        self.free = []
+        self.n = 0
+
+    def _grow(self, need_rows, need_ids):
+        if need_rows > len(self.xyz):
+            cap = max(need_rows, 2 * len(self.xyz))
+            # views handed out before a growth keep pointing at the old block: growth happens only when points are added
+            self.xyz = np.concatenate([self.xyz, np.zeros((cap - len(self.xyz), 3))])
+            self.tlen = np.concatenate([self.tlen, np.zeros(cap - len(self.tlen), np.int64)])
+        if need_ids > len(self.row_of):
+            self.row_of = np.concatenate([self.row_of, np.full(max(need_ids, 2 * len(self.row_of)) - len(self.row_of), -1, np.int64)])
+
+    def add(self, pid):
+        row = self.free.pop() if self.free else self.n
+        if row == self.n:
+            self.n += 1
+        self._grow(self.n, pid + 1)
+        self.row_of[pid] = row
+        return row
+
+    def remove(self, pid):
+        self.free.append(int(self.row_of[pid]))
+        self.row_of[pid] = -1
+
+    def rows(self, ids):
+        return self.row_of[np.asarray(ids, dtype=np.int64)]
 
 
 class Point2D:
@@ -180,8 +230,11 @@ class NumpyImage:
         return self.kps[np.asarray(idxs, dtype=np.int64)]
 
     def point3D_ids(self, idxs=None):
+        """pycolmap returns a list of ints; an index ARRAY gets an id array back (no per-element Python objects)."""
         if idxs is None:
             return [int(v) for v in self.kp_point3D]
+        if isinstance(idxs, np.ndarray):
+            return self.kp_point3D[idxs.astype(np.int64, copy=False)]
         return [int(v) for v in self.kp_point3D[np.asarray(idxs, dtype=np.int64)]]
 
 
@@ -213,7 +266,9 @@ class ObservationManager:
         s = self.scene
         pid = s._next_point3D_id
         s._next_point3D_id += 1
-        s.points3D[pid] = NumpyPoint3D(xyz, track)
+        row = s._store.add(pid)
+        s.points3D[pid] = NumpyPoint3D(xyz, track, s._store, row)
+        s._store.tlen[row] = track.length()
         for el in track.elements:
             s.images[el.image_id].kp_point3D[el.point2D_idx] = pid
         return pid
@@ -223,6 +278,7 @@ class ObservationManager:
         for el in s.points3D[pid].track.elements:
             s.images[el.image_id].kp_point3D[el.point2D_idx] = INVALID_POINT3D
         del s.points3D[pid]
+        s._store.remove(pid)
         s.point_covs.data.pop(pid, None)
 
     def delete_observation(self, image_id, point2D_idx):
@@ -234,6 +290,7 @@ class ObservationManager:
             self.delete_point3D(pid)
             return
         track.elements = [el for el in track.elements if not (el.image_id == image_id and el.point2D_idx == point2D_idx)]
+        s._store.tlen[s._store.row_of[pid]] = track.length()
         s.images[image_id].kp_point3D[point2D_idx] = INVALID_POINT3D
 
     def deregister_image(self, image_id):
@@ -259,6 +316,7 @@ class NumpyReconstruction:
         self.obs = HipObservationManager(self, ObservationManager(self))
         self.point_covs = PointCovs()
         self._next_point3D_id = 1
+        self._store = _PointStore()
 
     @property
     def registered_images(self):
@@ -269,7 +327,15 @@ class NumpyReconstruction:
         return self.images[imid].kps.copy()
 
     def point3D_coordinates(self, ids):
-        return np.array([self.points3D[int(i)].xyz for i in ids], dtype=np.float64).reshape(-1, 3)
+        """xyz of many points (reference reconstruction/base.py point3D_coordinates): one gather from the store"""
+        return self._store.xyz[self._store.rows(ids)].reshape(-1, 3)
+
+    # optional bulk accessors (not part of the reference's object model; the shim uses them when present)
+    def point3D_track_lengths(self, ids):
+        return self._store.tlen[self._store.rows(ids)]
+
+    def set_point3D_coordinates(self, ids, xyz):
+        self._store.xyz[self._store.rows(ids)] = xyz
 
     def project_image_3d_points(self, imid, pts3dids=None):
         """(pts2dids, pts3dids, kps, depth, success) — reference points3D_utils.py:9-25 + geometry.py:13-19."""

@@ -18,12 +18,7 @@ from oracle import cpu_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-class OracleBackend:
-    def solve(self, prob):
-        return O.solve(prob)
-
-    def point_covs(self, prob):
-        return O.point_covs(prob)
+from backends import OracleBackend  # noqa: E402
 
 
 def _bundle(sc):

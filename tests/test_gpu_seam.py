@@ -21,12 +21,7 @@ from test_observations_cpu import assert_same_state, make_dirty_scene, oracle_nu
 pytestmark = pytest.mark.gpu
 
 
-class OracleBackend:
-    def solve(self, prob):
-        return O.solve(prob)
-
-    def point_covs(self, prob):
-        return O.point_covs(prob)
+from backends import OracleBackend  # noqa: E402
 
 
 def _oracle_side(sc):

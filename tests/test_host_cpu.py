@@ -15,14 +15,7 @@ from mpsfm_amd.synthetic import make_scene
 from oracle import cpu_oracle as O
 
 
-class OracleBackend:
-    """Test-only backend: runs the assembled flat problem on the CPU oracle."""
-
-    def solve(self, prob):
-        return O.solve(prob)
-
-    def point_covs(self, prob):
-        return O.point_covs(prob)
+from backends import OracleBackend  # noqa: E402
 
 
 def test_bilinear_sampling_matches_grid_sample_golden():
