@@ -228,6 +228,66 @@ int mpsfm_filter_tracks(const mpsfm_tracks* tracks, const double* xyz /* [n_trac
                         int32_t device, double* max_tri_angle /* [n_tracks] */,
                         double* el_sq_err /* [n_el] */, uint8_t* el_front /* [n_el] */);
 
+/* -- row f2: track-graph logic of pycolmap.IncrementalTriangulator as MpsfmTriangulator drives it
+ *    (mpsfm/sfm/mapper/triangulator.py:32-48, 88-100, 123, 165-175): Find / Create / Continue, Complete, Merge,
+ *    Retriangulate with the fork's ignore_image_ids.  COLMAP 3.11 semantics (the fork's source is not in the reference
+ *    tree: parity unpinned).  The scene stays with the caller: it hands over the keypoints + correspondence graph once
+ *    and the mutable state before a call; every call leaves an operation log the caller replays on its
+ *    ObservationManager (add_point3D / add_observation / delete_point3D).  Keypoints are addressed by their global
+ *    index kp_start[image] + point2D_idx; points by their index in the state's arrays (new points continue that range). */
+typedef struct mpsfm_tri_options {       /* pycolmap.IncrementalTriangulatorOptions fields used by the calls below */
+  int32_t max_transitivity;              /* 1   (only the direct correspondences are implemented)                 */
+  double create_max_angle_error;         /* 2.0 degrees                                                            */
+  double continue_max_angle_error;       /* 2.0                                                                    */
+  double merge_max_reproj_error;         /* 4.0 px                                                                 */
+  double complete_max_reproj_error;      /* 4.0 px                                                                 */
+  int32_t complete_max_transitivity;     /* 5                                                                      */
+  double re_max_angle_error;             /* 5.0                                                                    */
+  double re_min_ratio;                   /* 0.2                                                                    */
+  int32_t re_max_trials;                 /* 1                                                                      */
+  double min_angle;                      /* 1.5 (the mapper overrides it to 0.001, mapper/base.py:35-40)          */
+  int32_t ignore_two_view_tracks;        /* 1   (the mapper overrides it to 0)                                     */
+} mpsfm_tri_options;
+typedef struct mpsfm_tri_graph {
+  int32_t n_images;
+  const int64_t* kp_start;   /* [n_images+1] */
+  const double* kp_xy;       /* [n_kp][2] Point2D.xy */
+  const double* cam_intr;    /* [n_images][4] PINHOLE fx fy cx cy */
+  const int64_t* corr_start; /* [n_kp+1] CSR of the correspondence graph */
+  const int64_t* corr_kp;    /* [n_corr] matched keypoint (global index) */
+} mpsfm_tri_graph;
+typedef struct mpsfm_tri_state {
+  const uint8_t* registered;      /* [n_images] image.has_pose */
+  const double* cam_quat_xyzw;    /* [n_images][4] */
+  const double* cam_t;            /* [n_images][3] */
+  const int64_t* kp_point;        /* [n_kp] index of the keypoint's 3-D point in xyz, or -1 */
+  int64_t n_points;
+  const double* xyz;              /* [n_points][3] */
+} mpsfm_tri_state;
+typedef struct mpsfm_triangulator mpsfm_triangulator;
+enum mpsfm_tri_op { MPSFM_TRI_ADD_POINT = 0 /* a = point, b = track length, xyz */, MPSFM_TRI_ADD_OBS = 1 /* a = point, b = keypoint */,
+                    MPSFM_TRI_DELETE_POINT = 2 /* a = point */ };
+
+void mpsfm_tri_default_options(mpsfm_tri_options* o);
+int mpsfm_triangulator_create(const mpsfm_tri_graph* graph, int32_t device, mpsfm_triangulator** out);
+void mpsfm_triangulator_destroy(mpsfm_triangulator* h);
+int mpsfm_triangulator_set_state(mpsfm_triangulator* h, const mpsfm_tri_state* state);
+int mpsfm_triangulator_triangulate_image(mpsfm_triangulator* h, const mpsfm_tri_options* o, int32_t image, int64_t* count);
+int mpsfm_triangulator_complete_image(mpsfm_triangulator* h, const mpsfm_tri_options* o, int32_t image, int64_t* count);
+/* n < 0: every track (complete_all_tracks / merge_all_tracks) */
+int mpsfm_triangulator_complete_tracks(mpsfm_triangulator* h, const mpsfm_tri_options* o, const int64_t* points, int64_t n, int64_t* count);
+int mpsfm_triangulator_merge_tracks(mpsfm_triangulator* h, const mpsfm_tri_options* o, const int64_t* points, int64_t n, int64_t* count);
+int mpsfm_triangulator_retriangulate(mpsfm_triangulator* h, const mpsfm_tri_options* o, const int32_t* ignore_images, int32_t n_ignore,
+                                     int64_t* count);
+/* operation log of the last call, in the order the operations happened */
+int64_t mpsfm_triangulator_num_ops(mpsfm_triangulator* h);
+int64_t mpsfm_triangulator_num_points(mpsfm_triangulator* h);
+int mpsfm_triangulator_get_ops(mpsfm_triangulator* h, int32_t* type, int64_t* a, int64_t* b, double* xyz /* [n_ops][3] */);
+/* track elements (global keypoint indices) of the log's ADD_POINT operations, concatenated in log order */
+int64_t mpsfm_triangulator_num_op_elements(mpsfm_triangulator* h);
+int mpsfm_triangulator_get_op_elements(mpsfm_triangulator* h, int64_t* els);
+int mpsfm_triangulator_stats(mpsfm_triangulator* h, int64_t* batch, int64_t* batch_hits, int64_t* host_estimates);
+
 /* -- row f3: depth-block selection of Optimizer.__build_problem for a whole bundle in one launch
  *    (mpsfm/sfm/mapper/bundle_adjustment.py:124-161) and the whitened log-depth errors of
  *    update_truncation_multiplier (:295-333).  Per keypoint that has a 3-D point: bilinear samples of the validity

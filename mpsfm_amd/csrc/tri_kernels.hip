@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tri_math.h"
 
 namespace mpsfm {
 
@@ -91,49 +92,6 @@ __global__ void k_pcov_invert(int np, const double* H, double* cov) {
 }
 
 // ---- triangulation -------------------------------------------------------------------------------
-// smallest eigenvector of a symmetric 4x4 by cyclic Jacobi rotations
-__device__ inline void sym4_min_eigvec(double A[4][4], double v[4]) {
-  double Q[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-  for (int sweep = 0; sweep < 30; ++sweep) {
-    double off = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
-    if (off < 1e-300) break;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int q = p + 1; q < 4; ++q) {
-        const double apq = A[p][q];
-        if (apq == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const double qkp = Q[k][p], qkq = Q[k][q];
-          Q[k][p] = c * qkp - s * qkq; Q[k][q] = s * qkp + c * qkq;
-        }
-      }
-  }
-  double best = A[0][0];
-  v[0] = Q[0][0]; v[1] = Q[1][0]; v[2] = Q[2][0]; v[3] = Q[3][0];
-#pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (A[i][i] < best) { best = A[i][i]; v[0] = Q[0][i]; v[1] = Q[1][i]; v[2] = Q[2][i]; v[3] = Q[3][i]; }
-}
-
 struct TrackArgs {
   int32_t n_tracks;
   const double* q; const double* t; const double* intr; const int32_t* intr_idx;

@@ -66,6 +66,11 @@ def triangulate_points(scene, point3D_ids, device: int = 0) -> np.ndarray:
     return capi.triangulate_tracks(tr, device)
 
 
+_TRI_OPTION_KEYS = ("max_transitivity", "create_max_angle_error", "continue_max_angle_error", "merge_max_reproj_error",
+                    "complete_max_reproj_error", "complete_max_transitivity", "re_max_angle_error", "re_min_ratio", "re_max_trials",
+                    "min_angle", "ignore_two_view_tracks")
+
+
 class ColmapTriangulatorWrapper:
     def __getattr__(self, name):
         if name in self.__dict__:
@@ -89,16 +94,27 @@ class MpsfmTriangulator(BaseClass, ColmapTriangulatorWrapper):
 
     def _init(self, mpsfm_rec, correspondences_graph=None, engine=None, **kwargs):
         self.mpsfm_rec = mpsfm_rec
-        self._triangulator = engine  # IncrementalTriangulator-compatible object (graph logic)
+        self.correspondences_graph = correspondences_graph
+        # the track-graph engine: anything with pycolmap.IncrementalTriangulator's method names; by default the native
+        # one of this repository (built on first use: the scene's keypoints must all be there by then)
+        self._triangulator = engine
         self.device = int(kwargs.get("device", 0))
         opts = self.conf.colmap_options
-        self.options = dict(opts) if isinstance(opts, dict) else {}
+        if isinstance(opts, dict):
+            self.options = dict(opts)
+        elif opts is None or isinstance(opts, str):
+            self.options = {}
+        else:  # an OmegaConf node or a pycolmap options object: its triangulator fields (reference :34-40)
+            self.options = {k: (opts[k] if hasattr(opts, "__getitem__") else getattr(opts, k)) for k in _TRI_OPTION_KEYS
+                            if (k in opts if hasattr(opts, "__contains__") else hasattr(opts, k))}
 
     def _require_engine(self):
         if self._triangulator is None:
-            raise NotImplementedError(
-                "track finding/merging is COLMAP graph logic (SURVEY.md §8f f2): pass an "
-                "IncrementalTriangulator-compatible `engine`")
+            if self.correspondences_graph is None:
+                raise ValueError("MpsfmTriangulator needs the correspondence graph (reference mapper/base.py:183) or an `engine`")
+            from .track_engine import HipIncrementalTriangulator
+
+            self._triangulator = HipIncrementalTriangulator(self.correspondences_graph, self.mpsfm_rec, self.device)
 
     # -- depth lifting of low-parallax points (reference :49-83 and :125-161) ----------------------
     def _lift_points(self, point3D_ids):

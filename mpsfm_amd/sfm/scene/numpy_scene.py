@@ -281,6 +281,13 @@ class ObservationManager:
         s._store.remove(pid)
         s.point_covs.data.pop(pid, None)
 
+    def add_observation(self, pid, track_el):
+        """COLMAP ObservationManager::AddObservation"""
+        s = self.scene
+        s.points3D[pid].track.add_element(track_el.image_id, track_el.point2D_idx)
+        s._store.tlen[s._store.row_of[pid]] = s.points3D[pid].track.length()
+        s.images[track_el.image_id].kp_point3D[track_el.point2D_idx] = pid
+
     def delete_observation(self, image_id, point2D_idx):
         """COLMAP ObservationManager::DeleteObservation: a track of length <= 2 goes away with its point."""
         s = self.scene
@@ -307,7 +314,45 @@ class ObservationManager:
         return n
 
 
+class NumpyCorrespondenceGraph:
+    """Stand-in for pycolmap.CorrespondenceGraph with the method names the reference uses on it
+    (mpsfm/sfm/scene/correspondences/base.py:55-61, 124-138)."""
+
+    def __init__(self):
+        self.num_kp, self.matches = {}, {}
+
+    def add_image(self, image_id, num_points2D):
+        self.num_kp[int(image_id)] = int(num_points2D)
+
+    def add_correspondences(self, image_id1, image_id2, matches):
+        m = np.asarray(matches, np.int64).reshape(-1, 2)
+        a, b = int(image_id1), int(image_id2)
+        if a > b:
+            a, b, m = b, a, m[:, ::-1]
+        self.matches[(a, b)] = np.concatenate([self.matches[(a, b)], m]) if (a, b) in self.matches else m.copy()
+
+    def finalize(self):
+        pass
+
+    def image_pairs(self):
+        return sorted(self.matches)
+
+    def find_correspondences_between_images(self, image_id1, image_id2):
+        a, b = int(image_id1), int(image_id2)
+        if a <= b:
+            return self.matches.get((a, b), np.zeros((0, 2), np.int64))
+        return self.matches.get((b, a), np.zeros((0, 2), np.int64))[:, ::-1]
+
+    def num_correspondences_between_images(self, image_id1, image_id2):
+        return len(self.find_correspondences_between_images(image_id1, image_id2))
+
+    def num_correspondences_for_image(self, image_id):
+        return sum(len(m) for (a, b), m in self.matches.items() if int(image_id) in (a, b))
+
+
 class NumpyReconstruction:
+    Track, TrackElement = Track, TrackElement  # the element types obs.add_point3D / add_observation take (pycolmap.Track / TrackElement)
+
     def __init__(self):
         self.images: dict[int, NumpyImage] = {}
         self.points3D: dict[int, NumpyPoint3D] = {}
@@ -409,7 +454,7 @@ class NumpyReconstruction:
 
 
 def scene_from_problem(prob, truth=None, map_size=(129, 97), image_size=(1600.0, 1200.0), seed=0,
-                       prior_noise=0.0263, first_image_id=1):
+                       prior_noise=0.0263, first_image_id=1, with_points=True):
     """Builds a NumpyReconstruction from a synthetic BAProblem (mpsfm_amd.synthetic.make_scene):
     one keypoint per observation, per-image prior depth maps splatted from the true camera-frame
     depths (so the sampled priors are roughly right), variance map from the reference's model."""
@@ -456,8 +501,10 @@ def scene_from_problem(prob, truth=None, map_size=(129, 97), image_size=(1600.0,
     for c in range(n_cams):
         idx = order[starts[c]:starts[c + 1]]
         local_idx[idx] = np.arange(len(idx))
+    scene._obs_image = np.array([imids[int(c)] for c in prob.obs_cam], np.int64)  # observation -> (image id, point2D idx)
+    scene._obs_point2D = local_idx
     pid_of = {}
-    for p in range(prob.n_pts):
+    for p in range(prob.n_pts if with_points else 0):
         obs = pt_order[pstarts[p]:pstarts[p + 1]]
         if len(obs) == 0:
             continue
@@ -467,3 +514,43 @@ def scene_from_problem(prob, truth=None, map_size=(129, 97), image_size=(1600.0,
         pid_of[p] = scene.obs.add_point3D(prob.pts[p], tr)
     scene._pid_of_problem_point = pid_of
     return scene
+
+
+def correspondences_from_problem(scene, prob, false_matches=0, seed=0):
+    """A correspondence graph for a scene built by scene_from_problem: every pair of observations of one landmark is a
+    match (what exhaustive matching + geometric verification would find), plus `false_matches` random wrong ones."""
+    cg = NumpyCorrespondenceGraph()
+    for imid, im in scene.images.items():
+        cg.add_image(imid, len(im.kps))
+    order = np.argsort(prob.obs_pt, kind="stable")
+    start = np.searchsorted(prob.obs_pt[order], np.arange(prob.n_pts + 1))
+    im_of, kp_of = scene._obs_image[order], scene._obs_point2D[order]
+    length = np.diff(start)
+    pairs = {}
+    for L in np.unique(length):
+        if L < 2:
+            continue
+        pts = np.flatnonzero(length == L)
+        base = start[pts][:, None] + np.arange(L)[None, :]          # [n, L] observation slots of these landmarks
+        for a in range(L):
+            for b in range(a + 1, L):
+                i1, i2 = im_of[base[:, a]], im_of[base[:, b]]
+                k1, k2 = kp_of[base[:, a]], kp_of[base[:, b]]
+                swap = i1 > i2
+                i1, i2, k1, k2 = np.where(swap, i2, i1), np.where(swap, i1, i2), np.where(swap, k2, k1), np.where(swap, k1, k2)
+                key = i1 * (1 << 32) + i2
+                for kk in np.unique(key):
+                    sel = key == kk
+                    pairs.setdefault((int(kk >> 32), int(kk & 0xffffffff)), []).append(np.stack([k1[sel], k2[sel]], 1))
+    rng = np.random.default_rng(seed)
+    ids = sorted(scene.images)
+    for _ in range(false_matches):
+        a, b = sorted(rng.choice(len(ids), 2, replace=False))
+        ia, ib = ids[a], ids[b]
+        pairs.setdefault((ia, ib), []).append(np.array([[rng.integers(len(scene.images[ia].kps)), rng.integers(len(scene.images[ib].kps))]]))
+    for (ia, ib), ms in pairs.items():
+        if ia == ib:
+            continue
+        cg.add_correspondences(ia, ib, np.unique(np.concatenate(ms), axis=0))
+    cg.finalize()
+    return cg

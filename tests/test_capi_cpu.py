@@ -24,6 +24,25 @@ def test_library_exports_every_declared_symbol():
     assert L.mpsfm_abi_version() == 1
 
 
+def test_triangulator_and_gather_entry_points_check_arguments_first():
+    import ctypes as C
+
+    from mpsfm_amd.sfm.mapper.track_engine import CTriOptions
+
+    L = capi.lib()
+    o = CTriOptions()
+    L.mpsfm_tri_default_options(C.byref(o))
+    assert (o.max_transitivity, o.create_max_angle_error, o.merge_max_reproj_error, o.complete_max_transitivity) == (1, 2.0, 4.0, 5)
+    assert (o.re_max_angle_error, o.re_min_ratio, o.re_max_trials, o.min_angle, o.ignore_two_view_tracks) == (5.0, 0.2, 1, 1.5, 1)
+    L.mpsfm_triangulator_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    h = C.c_void_p(None)
+    assert L.mpsfm_triangulator_create(None, 0, C.byref(h)) == -1
+    L.mpsfm_triangulator_set_state.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.mpsfm_triangulator_set_state(None, None) == -1
+    L.mpsfm_depth_blocks.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 6
+    assert L.mpsfm_depth_blocks(None, 0, None, None, None, None, None, None) == -1
+
+
 def test_default_options_are_ceres_defaults():
     o = capi.default_options()
     assert o.max_num_iterations == 50

@@ -102,7 +102,7 @@ def test_triangulator_lifts_low_parallax_points():
         assert z > 0
     xyz = triangulate_points(sc, ids[:5] if all(i in sc.points3D for i in ids[:5]) else list(sc.points3D)[:5])
     assert xyz.shape == (5, 3)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):  # neither a correspondence graph nor an engine: nothing to walk
         tri.complete_and_merge_all_tracks()
 
 
