@@ -160,7 +160,8 @@ def main():
             pass
 
     out = {
-        "metric": "BA residual-evals/sec (LM iterations/sec alongside), 200 imgs / 150k pts prior-BA",
+        "metric": f"BA residual-evals/sec (LM iterations/sec alongside), {CONFIGS[args.config][0]} imgs / {CONFIGS[args.config][1] // 1000}k pts "
+                  + ("prior-BA" if CONFIGS[args.config][2] else "reprojection-only BA"),
         "value": revals / dt,
         "unit": "residual-block evals/s",
         "lm_iterations_per_s": iters / dt,
