@@ -40,7 +40,7 @@ void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const d
                        const int32_t* intr_idx = nullptr, double* camtab2 = nullptr, int* chol_fail = nullptr);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov = nullptr);
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const DenseEnvelope* env);
 size_t dense_work_doubles(int nt);
 double* dense_pinv(double* work, int nt, const DenseOverlap* ov);
 
@@ -312,7 +312,10 @@ using namespace mpsfm;
 struct mpsfm_ba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
-  DenseOverlap ov;  // second stream for the dense factorisation of large systems (nt > 64)
+  DenseOverlap ov;  // second stream for the dense factorisation in outer panels (MPSFM_CHOL_NB)
+  DenseEnvelope env;  // block skyline of the reduced system
+  std::vector<int32_t> env_rows_start, env_prow_start, env_rows;
+  int32_t *d_env_first = nullptr, *d_env_rows = nullptr, *d_env_prow = nullptr;
   bool own_stream = false;
   mpsfm_ba_options opt{};
   LossParams loss{};
@@ -369,7 +372,8 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_cs, h->d_camtab, h->d_camtab2, h->d_intr_idx, h->d_cam_slot, h->d_ps, h->d_diagV, h->d_chunks,
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
-                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl};
+                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
+                  h->d_env_first, h->d_env_rows, h->d_env_prow};
   for (void* p : ptrs) cached_free(p);
   release_pinned(h->h_scal);
   for (auto& e : h->ev) release_event(e, true);
@@ -901,6 +905,80 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     std::fprintf(stderr, "[mpsfm_ba] build: %zu chunks; per chunk: %.1f records, %.1f landmarks, %.1f cameras (max %d), %.1f work items (max %d), %.1f pairs\n",
                  chunks.size(), sr / n, sp / n, sc / n, mc, sb / n, mb, se / n);
   }
+  // -- block skyline of the reduced camera system (DenseEnvelope): which 6x6 blocks of S can be nonzero follows from the
+  //    static Schur pair tables; first_blk[c] = lowest camera slot that shares a landmark with slot c
+  {
+    const int ncv = h->ncv, nt = h->nt, n = h->n;
+    std::vector<int32_t> first_blk((size_t)std::max(ncv, 1));
+    for (int c = 0; c < ncv; ++c) first_blk[(size_t)c] = c;
+    for (const ChunkHdr& H : chunks) {
+      const int32_t* cams = chunk_cams.data() + H.cam0;
+      for (int b = 0; b < H.nblk; ++b) {
+        const uint32_t d = blk_desc[(size_t)H.blk0 + (size_t)b];
+        const int si = cams[d & 0xff], sj = cams[(d >> 8) & 0xff];
+        const int lo = std::min(si, sj), hi = std::max(si, sj);
+        first_blk[(size_t)hi] = std::min(first_blk[(size_t)hi], lo);
+      }
+    }
+    for (const LongHdr& L : lhdr) {  // a long track couples all its variable cameras
+      int lo = INT32_MAX;
+      for (int r = 0; r < L.kv; ++r) lo = std::min(lo, slot[rec_cam[(size_t)L.rec0 + (size_t)r]]);
+      for (int r = 0; r < L.kv; ++r) { int32_t& f = first_blk[(size_t)slot[rec_cam[(size_t)L.rec0 + (size_t)r]]]; f = std::min(f, lo); }
+    }
+    const char* envs = std::getenv("MPSFM_CHOL_ENVELOPE");
+    if (envs && std::atoi(envs) == 0) std::fill(first_blk.begin(), first_blk.end(), 0);  // A/B: treat S as dense
+    if (h->opt.allreduce && ncv > 0) {
+      // landmark shards see different camera pairs: every rank needs the UNION.  The hook only sums, so the minimum over
+      // ranks is found by bisection on indicator sums (the same number of rounds on every rank).
+      std::vector<double> lo((size_t)ncv, 0.0), hi((size_t)ncv), ind((size_t)ncv);
+      for (int c = 0; c < ncv; ++c) hi[(size_t)c] = (double)c;
+      int rounds = 1;
+      while ((1 << rounds) < ncv + 1) ++rounds;
+      for (int it = 0; it < rounds; ++it) {
+        for (int c = 0; c < ncv; ++c) ind[(size_t)c] = first_blk[(size_t)c] <= (int)std::floor(0.5 * (lo[(size_t)c] + hi[(size_t)c])) ? 1.0 : 0.0;
+        if (int rc2 = allreduce_host(h, ind.data(), ncv)) return rc2;
+        for (int c = 0; c < ncv; ++c) {
+          const double mid = std::floor(0.5 * (lo[(size_t)c] + hi[(size_t)c]));
+          if (ind[(size_t)c] > 0.0) hi[(size_t)c] = mid; else lo[(size_t)c] = std::min(mid + 1.0, hi[(size_t)c]);
+        }
+      }
+      for (int c = 0; c < ncv; ++c) first_blk[(size_t)c] = (int32_t)hi[(size_t)c];
+    }
+    std::vector<int32_t> first((size_t)nt + 1, 0);
+    for (int ti = 0; ti < nt; ++ti) {
+      int f = ti;
+      for (int r = ti * 32; r < std::min(n, ti * 32 + 32); ++r) f = std::min(f, (6 * first_blk[(size_t)(r / 6)]) / 32);
+      first[(size_t)ti] = f;
+    }
+    first[(size_t)nt] = 0;  // the right-hand-side row
+    h->env_prow_start.assign((size_t)nt + 1, 0);
+    h->env_rows_start.assign((size_t)std::max(nt, 1), 0);
+    std::vector<int32_t> prow;
+    h->env_rows.clear();
+    for (int j = -1; j <= nt - 2; ++j) {
+      h->env_prow_start[(size_t)j + 1] = (int32_t)prow.size();
+      for (int ti = j + 1; ti <= nt; ++ti) if (first[(size_t)ti] <= j + 1) prow.push_back(ti);
+      if (j >= 0) {
+        h->env_rows_start[(size_t)j] = (int32_t)h->env_rows.size();
+        for (int ti = j + 1; ti <= nt; ++ti) if (first[(size_t)ti] <= j) h->env_rows.push_back(ti);
+      }
+    }
+    h->env_prow_start[(size_t)nt] = (int32_t)prow.size();
+    if (nt >= 1) h->env_rows_start[(size_t)nt - 1] = (int32_t)h->env_rows.size();
+    int rc2 = 0;
+    if ((rc2 = dev_upload(&h->d_env_first, first))) return rc2;
+    if ((rc2 = dev_upload(&h->d_env_rows, h->env_rows))) return rc2;
+    if ((rc2 = dev_upload(&h->d_env_prow, prow))) return rc2;
+    h->env.valid = nt >= 1;
+    h->env.d_first = h->d_env_first; h->env.d_rows = h->d_env_rows; h->env.d_prow = h->d_env_prow;
+    h->env.h_rows_start = h->env_rows_start.data(); h->env.h_prow_start = h->env_prow_start.data(); h->env.h_rows = h->env_rows.data();
+    if (h->opt.verbose >= 2) {
+      int64_t inside = 0;
+      for (int ti = 0; ti < nt; ++ti) inside += ti - first[(size_t)ti] + 1;
+      std::fprintf(stderr, "[mpsfm_ba] build: block skyline %lld of %lld tiles\n", (long long)inside, (long long)nt * (nt + 1) / 2);
+    }
+  }
+
   // -- fixed records (landmark index re-ordered)
   std::vector<int32_t> fx_cam, fx_pt; std::vector<uint32_t> fx_meta; std::vector<double> fx_xy, fx_d, fx_m, fx_a;
   for (size_t i = 0; i < fixed.size(); ++i) {
@@ -1091,7 +1169,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
     AssembleArgs as{h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
                     h->opt.max_lm_diagonal, h->d_A, dense_pinv(h->d_dwork, h->nt, &h->ov)};
     launch_assemble(as, s);
-    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov);
+    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->env);
   }
   return 0;
 }

@@ -346,7 +346,7 @@ extern "C" int mpsfm_debug_set_chol_trace(long long* dev_buf) {
 //   kStepNoOwnUpdate  the panel column j+1 has already received column j (first step of an outer panel),
 //   kStepBig          no factorisation: every tile (ti, tk), j < tk <= tk_max, gets columns c0..j at once
 //                     (one load and one store of the tile for a rank-32*(j-c0+1) update).
-constexpr int kStepNoOwnUpdate = 1, kStepBig = 2, kStepTri = 4;
+constexpr int kStepNoOwnUpdate = 1, kStepBig = 2, kStepEnv = 4;
 // Inverse propagation (plain path only, Pinv != NULL).  The back substitution y = L^-T z is a chain of nt dependent
 // tile solves — ten launches of ~10 us at nt = 38.  Instead the steps also build, in the shadow of their
 // latency-bound panel factorisation, the accumulators  P(i,k) = sum_{j=k}^{i-1} L(i,j) X(j,k)  of the inverse
@@ -361,7 +361,7 @@ constexpr int kStepNoOwnUpdate = 1, kStepBig = 2, kStepTri = 4;
 #endif
 constexpr int kInvRows = MPSFM_INV_ROWS;  // rows i handled by one inverse-role workgroup (X(j,k) is formed once for all of them)
 constexpr int kStepThreads = 256;         // four waves: one 16 x 16 quadrant of a tile each
-__device__ __forceinline__ void inv_role(const double* A, const double* LinvT, double* Pinv, int nt, int j, int i0, int i1, int k,
+__device__ __forceinline__ void inv_role(const double* A, const double* LinvT, double* Pinv, int nt, int j, const int* irow, int ni_rows, int k,
                                          double (*s_B)[kTile + 1], double* s_C) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 1, ni = wave >> 1;
@@ -374,7 +374,7 @@ __device__ __forceinline__ void inv_role(const double* A, const double* LinvT, d
   double aop[kInvRows][8];
 #pragma unroll
   for (int r = 0; r < kInvRows; ++r) {
-    const int i = min(i0 + r, i1 - 1);
+    const int i = irow[min(r, ni_rows - 1)];
     quad_load(Pinv + lt_tile(i, k) * kTileElems, kTile, lane, mi, ni, acc[r]);
     const double* arow = A + lt_tile(i, j) * kTileElems + (16 * mi + m16) * kTile + kg;
 #pragma unroll
@@ -405,15 +405,20 @@ __device__ __forceinline__ void inv_role(const double* A, const double* LinvT, d
   for (int s = 0; s < 8; ++s) bT[s] = s_B[4 * s + kg][16 * ni + m16];
 #pragma unroll
   for (int r = 0; r < kInvRows; ++r) {
-    if (i0 + r >= i1) break;
+    if (r >= ni_rows) break;
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[r][s], bT[s], acc[r], 0, 0, 0);
-    quad_store(Pinv + lt_tile(i0 + r, k) * kTileElems, kTile, lane, mi, ni, acc[r]);
+    quad_store(Pinv + lt_tile(irow[r], k) * kTileElems, kTile, lane, mi, ni, acc[r]);
   }
 }
 
+struct StepEnv {  // the skyline rows of this step (kStepEnv), see DenseEnvelope
+  const int32_t* first; const int32_t* rows; const int32_t* prow;
+  int nr, np;
+};
+
 __global__ __launch_bounds__(kStepThreads) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg, int c0, int tk_max,
-                                                            int mode, double* Pinv, int cols) {
+                                                            int mode, double* Pinv, int cols, StepEnv E) {
   __shared__ double s_T[kTile][kTile + 1];
   __shared__ double s_X[kTile][kTile + 1];
   __shared__ __attribute__((aligned(16))) double s_Lt[kTile * kTile];
@@ -421,38 +426,35 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_step(double* A, double* L
   const int mi = wave & 1, ni = wave >> 1;  // this wave's quadrant
   if (dbg & 16) return;  // ablation: the launch chain alone
   int tk, ti;
-  if (mode & kStepTri) {
-    // plain step on a 1-D grid without idle workgroups: [panel tiles | trailing tiles | inverse roles]
-    const int npanel = nt - j;                 // ti = j+1 .. nt
-    const int m = nt - j - 2;                  // trailing tile columns j+2 .. nt-1; rows tk .. nt
-    const int ntrail = m > 0 ? m * (m + 3) / 2 : 0;
-    // order of dispatch = order of need: the panel column (the critical path), then the inverse roles (the longest
-    // workgroups), then the trailing tiles
-    const int nrows = nt - 1 - j;  // role rows i in (j, nt-1]
-    const int ngrp = (nrows + kInvRows - 1) / kInvRows;
-    const int nroles = (Pinv && j >= 0 && nrows > 0) ? ngrp * (j + 1) : 0;
+  bool upd_D = true, upd_X = true;  // whether column j reaches the diagonal tile / this workgroup's tile (skyline)
+  if (mode & kStepEnv) {
+    // plain step inside the block skyline, 1-D grid without idle workgroups: [panel tiles | inverse roles | trailing tiles]
+    const int off = (E.nr > 0 && E.rows[0] == j + 1) ? 1 : 0;  // row j+1 belongs to the panel, not to the trailing block
+    const int a = E.nr - off;                                   // trailing rows (the last one is the right-hand side)
+    const int ntrail = a > 0 ? a * (a + 1) / 2 : 0;
+    const int nrr = E.nr - 1;                                   // role rows: all of rows(j) but the right-hand side
+    const int ngrp = (nrr + kInvRows - 1) / kInvRows;
+    const int nroles = (Pinv && j >= 0 && nrr > 0) ? ngrp * (j + 1) : 0;
     int q = blockIdx.x;
-    if (q < npanel) {
-      tk = j + 1; ti = j + 1 + q;
-    } else if (q < npanel + nroles) {
-      const int role = q - npanel;
+    if (q < E.np) {
+      tk = j + 1; ti = E.prow[q];
+      upd_D = j >= 0 && E.first[tk] <= j;
+      upd_X = upd_D && E.first[ti] <= j;
+    } else if (q < E.np + nroles) {
+      const int role = q - E.np;
       if (dbg & 8) return;  // dbg 8: dispatch the roles, do nothing
-      const int i0 = j + 1 + (role % ngrp) * kInvRows;
-      inv_role(A, LinvT, Pinv, nt, j, i0, min(i0 + kInvRows, nt), role / ngrp, s_T, s_Lt);
+      const int g = role % ngrp;
+      inv_role(A, LinvT, Pinv, nt, j, E.rows + g * kInvRows, min(kInvRows, nrr - g * kInvRows), role / ngrp, s_T, s_Lt);
       return;
     } else {
-      q -= npanel + nroles;
+      q -= E.np + nroles;
       if (q >= ntrail) return;
-      const int tri = m * (m + 1) / 2;
-      int r, c;
-      if (q >= tri) { r = m; c = q - tri; }    // the right-hand-side tile row
-      else {
-        r = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-        while (r * (r + 1) / 2 > q) --r;
-        while ((r + 1) * (r + 2) / 2 <= q) ++r;
-        c = q - r * (r + 1) / 2;
-      }
-      tk = j + 2 + c; ti = j + 2 + r;
+      int r = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+      while (r * (r + 1) / 2 > q) --r;
+      while ((r + 1) * (r + 2) / 2 <= q) ++r;
+      const int c = q - r * (r + 1) / 2;
+      tk = E.rows[off + c]; ti = E.rows[off + r];
+      if (tk >= nt) return;  // (rhs, rhs) is not a tile
     }
   } else {
     tk = j + 1 + blockIdx.y;
@@ -486,13 +488,13 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_step(double* A, double* L
     v4d dacc, xacc;
     quad_load(A + lt_tile(tk, tk) * kTileElems, kTile, lane, mi, ni, dacc);
     if (!diag) quad_load(C, kTile, lane, mi, ni, xacc);
-    if (own_update) {
+    if (own_update && upd_D) {
       const double* Lk = A + lt_tile(tk, j) * kTileElems;
       double am[8], bn[8];
       quad_operand(Lk, lane, mi, am);
       quad_operand(Lk, lane, ni, bn);
       quad_gemm_sub(am, bn, dacc);
-      if (!diag) {
+      if (!diag && upd_X) {
         quad_operand(A + lt_tile(ti, j) * kTileElems, lane, mi, am);
         quad_gemm_sub(am, bn, xacc);
       }
@@ -696,52 +698,78 @@ static int dense_panel_width(int nt, const DenseOverlap* ov) {
 }
 // the accumulators of the inverse propagation, or NULL when this solve does not use them (outer panels, switched off)
 double* dense_pinv(double* work, int nt, const DenseOverlap* ov) {
-  if (nt <= 0 || nt > kPlainMaxTiles || (ov && ov->no_inverse) || dense_panel_width(nt, ov) < nt) return nullptr;
+  if (nt <= 0 || nt > kPlainMaxTiles || (ov && (ov->no_inverse || ov->nb > 0))) return nullptr;
   return work + (size_t)nt * kTileElems + 2 * (size_t)nt * kTile;
 }
 
 // ov (may be NULL): a second stream and events.  With it the update of an outer panel is split: the tile
 // columns of the NEXT panel are updated on the main stream (the factorisation needs them next), the columns
 // beyond run on the second stream under the next panel's factorisation steps.
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov) {
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov, const DenseEnvelope* env) {
   if (nt <= 0) return;
   double* LinvT = work;
   double* zbuf = work + (size_t)nt * kTileElems;
   double* wbuf = zbuf + (size_t)nt * kTile;
+  const StepEnv no_env{nullptr, nullptr, nullptr, 0, 0};
+  if (env && env->valid && !(ov && ov->nb > 0)) {
+    // Block-skyline factorisation: one launch per tile column, every launch a 1-D grid over the tiles that can be
+    // nonzero (DenseEnvelope).  What Ceres gets from its sparse Cholesky (reference bundle_adjustment.py:288,
+    // SPARSE_SCHUR): with cameras that only share landmarks with their neighbours most of S and of L is structurally
+    // zero — at C3 232 of 741 tiles are inside the skyline and the trailing updates shrink 14-fold.
+    double* Pinv = dense_pinv(work, nt, ov);
+    for (int j = -1; j <= nt - 2; ++j) {
+      StepEnv E;
+      E.first = env->d_first;
+      E.prow = env->d_prow + env->h_prow_start[j + 1];
+      E.np = env->h_prow_start[j + 2] - env->h_prow_start[j + 1];
+      E.rows = nullptr; E.nr = 0;
+      int grid = E.np;
+      if (j >= 0) {
+        E.rows = env->d_rows + env->h_rows_start[j];
+        E.nr = env->h_rows_start[j + 1] - env->h_rows_start[j];
+        const int off = (E.nr > 0 && env->h_rows[env->h_rows_start[j]] == j + 1) ? 1 : 0;
+        const int a = E.nr - off, nrr = E.nr - 1;
+        grid += (a > 0 ? a * (a + 1) / 2 : 0) + ((Pinv && nrr > 0) ? ((nrr + kInvRows - 1) / kInvRows) * (j + 1) : 0);
+      }
+      if (grid <= 0) continue;
+      hipLaunchKernelGGL(k_chol_step, dim3(grid), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, nt - 1,
+                         kStepEnv | (j < 0 ? kStepNoOwnUpdate : 0), Pinv, 1, E);
+    }
+    if (Pinv) {
+      hipLaunchKernelGGL(k_inv_w, dim3(nt), dim3(64), 0, s, A, LinvT, nt, n, wbuf, y);
+      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, Pinv, wbuf, nt, n, y);
+      return;
+    }
+    hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
+    for (int t1 = nt; t1 > 0; t1 -= kBsG) {
+      const int t0 = t1 - kBsG > 0 ? t1 - kBsG : 0;
+      hipLaunchKernelGGL(k_backsub_group, dim3(t0 > 0 ? t0 : 1), dim3(256), 0, s, A, LinvT, nt, n, t0, t1, zbuf, y);
+    }
+    return;
+  }
   // Outer panels of NB tile columns.  Inside a panel the plain right-looking steps run on the panel's
   // columns only; the tiles to the right then receive the whole panel in one launch (their load / store is
   // paid once per NB columns).  Up to 64 tile columns the matrix is one panel: exactly the plain algorithm.
   const int NB = dense_panel_width(nt, ov);
   const bool big_kernel = !ov || ov->big;
   const bool overlap = ov && ov->s2 && ov->overlap && big_kernel && NB < nt;
-  // inverse propagation: plain path only (one panel), unless switched off for A/B measurements
-  double* Pinv = dense_pinv(work, nt, ov);
   int npanel = 0;
   bool b_pending = false;  // an update on the second stream has been recorded in ov->evB and not yet waited for
   for (int p0 = 0; p0 < nt; p0 += NB, ++npanel) {
     const int pend = (p0 + NB - 1 < nt - 1) ? p0 + NB - 1 : nt - 1;
     // factor column p0 (its tiles already hold every earlier column); ti in [p0, nt]
     hipLaunchKernelGGL(k_chol_step, dim3(nt - p0 + 1, 1), dim3(kStepThreads), 0, s, A, LinvT, nt, p0 - 1, fail, g_dbg_flags, p0 - 1, p0,
-                       kStepNoOwnUpdate, (double*)nullptr, 1);
+                       kStepNoOwnUpdate, (double*)nullptr, 1, no_env);
     for (int j = p0; j <= pend - 1; ++j) {  // apply column j to columns (j, pend], factor column j+1; ti in [j+1, nt]
       const int rows = nt - j, cols = pend - j;
-      if (pend >= nt - 1) {
-        // plain step: every trailing column is touched; 1-D grid [panel | trailing triangle | inverse roles]
-        const int m = nt - j - 2;
-        const int ntrail = m > 0 ? m * (m + 3) / 2 : 0;
-        const int nroles = Pinv ? ((nt - 1 - j + kInvRows - 1) / kInvRows) * (j + 1) : 0;
-        hipLaunchKernelGGL(k_chol_step, dim3(rows + ntrail + nroles), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend,
-                           kStepTri, Pinv, cols);
-      } else {
-        hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0,
-                           (double*)nullptr, cols);
-      }
+      hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0,
+                         (double*)nullptr, cols, no_env);
     }
     if (pend >= nt - 1) break;
     // columns (pend, nt-1] receive the panel p0..pend; ti in [pend+1, nt]
     if (!big_kernel) {
       hipLaunchKernelGGL(k_chol_step, dim3(nt - pend, nt - 1 - pend), dim3(kStepThreads), 0, s, A, LinvT, nt, pend, fail, g_dbg_flags, p0, nt - 1,
-                         kStepBig, (double*)nullptr, nt - 1 - pend);
+                         kStepBig, (double*)nullptr, nt - 1 - pend, no_env);
     } else if (!overlap) {
       launch_big(A, nt, pend, p0, pend + 1, nt - 1, s);
     } else {
@@ -765,11 +793,6 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   if (overlap && npanel > 0) {
     // everything queued on the second stream must be complete before the substitution (and the next assemble)
     for (int k = 0; k < 4; ++k) (void)hipStreamWaitEvent(s, ov->evB[k], 0);
-  }
-  if (Pinv) {
-    hipLaunchKernelGGL(k_inv_w, dim3(nt), dim3(64), 0, s, A, LinvT, nt, n, wbuf, y);
-    hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, Pinv, wbuf, nt, n, y);
-    return;
   }
   hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
   for (int t1 = nt; t1 > 0; t1 -= kBsG) {
