@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
         }
         if (MODE == MODE_FULL) {
           // g_c and the upper triangle of U_c (21 values, packed row-major a <= b)
-          double* gS = &A.Sblk[ut_block(slot, slot, A.ncv) * 36];
+          double* gS = &A.Sblk[sky_block(A.sky, slot, slot) * 36];
           int u = 0;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
             const int li = desc & 0xff, lj = (desc >> 8) & 0xff;
             const int ra = el / 6, cb = el - ra * 6;
             if (v != 0.0 && (li != lj || cb >= ra))  // diagonal blocks keep their upper triangle only
-              atomicAdd(&A.Sblk[ut_block(s_slot[li], s_slot[lj], A.ncv) * 36 + el], -v);
+              atomicAdd(&A.Sblk[sky_block(A.sky, s_slot[li], s_slot[lj]) * 36 + el], -v);
           }
         }
         __syncthreads();
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       if (lc < ncam && v != 0.0) {
         int u = idx - lc * 21, i = 0;
         while (u >= 6 - i) { u -= 6 - i; ++i; }  // packed (i, j >= i) -> i, j = i + u
-        atomicAdd(&A.Sblk[ut_block(s_slot[lc], s_slot[lc], A.ncv) * 36 + i * 6 + i + u], v);
+        atomicAdd(&A.Sblk[sky_block(A.sky, s_slot[lc], s_slot[lc]) * 36 + i * 6 + i + u], v);
         if (u == 0) atomicAdd(&A.diagU[(size_t)s_slot[lc] * 6 + i], v);  // diagonal entry of U
       }
     }
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void k_long_track_sweep(SweepArgs A) {
       for (int i = 0; i < 6; ++i)
         atomicAdd(&A.diagU[(size_t)slot * 6 + i], L.Jc[i] * L.Jc[i] + L.Jc[6 + i] * L.Jc[6 + i] + L.Jc[12 + i] * L.Jc[12 + i]);
       if (MODE == MODE_FULL) {
-        double* gS = &A.Sblk[ut_block(slot, slot, A.ncv) * 36];
+        double* gS = &A.Sblk[sky_block(A.sky, slot, slot) * 36];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           atomicAdd(&A.gc[(size_t)slot * 6 + i], L.Jc[i] * L.r[0] + L.Jc[6 + i] * L.r[1] + L.Jc[12 + i] * L.r[2]);
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(kThreads) void k_long_track_sweep(SweepArgs A) {
       for (int a = 0; a < 6; ++a) sym3_mul(Vi, wi[a * 3], wi[a * 3 + 1], wi[a * 3 + 2], &Y[a * 3]);
 #pragma unroll
       for (int k = 0; k < 18; ++k) Wj[k] = wj[k];
-      double* dst = &A.Sblk[ut_block(si, sj, A.ncv) * 36];
+      double* dst = &A.Sblk[sky_block(A.sky, si, sj) * 36];
       if (si != sj) {
 #pragma unroll
         for (int a = 0; a < 6; ++a)

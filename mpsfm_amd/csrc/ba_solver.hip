@@ -316,6 +316,10 @@ struct mpsfm_ba_handle {
   DenseEnvelope env;  // block skyline of the reduced system
   std::vector<int32_t> env_rows_start, env_prow_start, env_rows;
   int32_t *d_env_first = nullptr, *d_env_rows = nullptr, *d_env_prow = nullptr;
+  std::vector<int32_t> sky_first;   // block skyline of S (BlockSky), host copies
+  std::vector<int64_t> sky_start;
+  int32_t* d_sky_first = nullptr;
+  int64_t* d_sky_start = nullptr;
   bool own_stream = false;
   mpsfm_ba_options opt{};
   LossParams loss{};
@@ -373,7 +377,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
-                  h->d_env_first, h->d_env_rows, h->d_env_prow};
+                  h->d_env_first, h->d_env_rows, h->d_env_prow, h->d_sky_first, h->d_sky_start};
   for (void* p : ptrs) cached_free(p);
   release_pinned(h->h_scal);
   for (auto& e : h->ev) release_event(e, true);
@@ -944,6 +948,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       }
       for (int c = 0; c < ncv; ++c) first_blk[(size_t)c] = (int32_t)hi[(size_t)c];
     }
+    h->sky_first = first_blk;
+    h->sky_start.assign((size_t)ncv + 1, 0);
+    for (int c = 0; c < ncv; ++c) h->sky_start[(size_t)c + 1] = h->sky_start[(size_t)c] + (c - first_blk[(size_t)c] + 1);
+    if (int rc2 = dev_upload(&h->d_sky_first, h->sky_first)) return rc2;
+    if (int rc2 = dev_upload(&h->d_sky_start, h->sky_start)) return rc2;
     std::vector<int32_t> first((size_t)nt + 1, 0);
     for (int ti = 0; ti < nt; ++ti) {
       int f = ti;
@@ -1027,7 +1036,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_cs, ncs * 6))) return rc;
   if ((rc = dev_alloc(&h->d_camtab, ncs * kCamRec))) return rc;
   if ((rc = dev_alloc(&h->d_camtab2, ncs * kCamRec))) return rc;
-  h->sblk_count = (int64_t)h->ncv * (h->ncv + 1) / 2 * 36;
+  h->sblk_count = h->sky_start[(size_t)h->ncv] * 36;
   h->red_count = h->sblk_count + 3 * (int64_t)h->n + SC_COUNT;
   if ((rc = dev_alloc(&h->d_red, (size_t)h->red_count))) return rc;
   h->d_Sblk = h->d_red; h->d_gc = h->d_red + h->sblk_count; h->d_wv = h->d_gc + h->n; h->d_diagU = h->d_wv + h->n;
@@ -1109,6 +1118,7 @@ static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius) {
   a.camtab = h->d_camtab; a.pts = h->d_pts; a.ps = h->d_ps; a.loss = h->loss;
   a.radius = radius; a.min_diag = h->opt.min_lm_diagonal; a.max_diag = h->opt.max_lm_diagonal; a.ncv = h->ncv; a.dbg = (g_dbg_flags >> 8) & 0xff;
   a.lhdr = h->d_lhdr; a.nlong = h->nlong; a.nchunks = h->nchunks; a.cam_slot = h->d_cam_slot; a.wl = h->d_wl;
+  a.sky = BlockSky{h->d_sky_first, h->d_sky_start};
   a.Sblk = h->d_Sblk; a.gc = h->d_gc; a.wv = h->d_wv; a.diagU = h->d_diagU; a.part = h->d_part; a.diagV = h->d_diagV;
   a.yc = h->d_yc; a.camtab2 = h->d_camtab2; a.pts2 = h->d_pts2; a.part2 = h->d_part2;
   return a;
@@ -1166,7 +1176,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
   hipStream_t s = h->stream;
   // d_fail is zero here: cleared at creation and re-armed by k_cam_update after every read
   if (h->n > 0) {
-    AssembleArgs as{h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
+    AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
                     h->opt.max_lm_diagonal, h->d_A, dense_pinv(h->d_dwork, h->nt, &h->ov)};
     launch_assemble(as, s);
     launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->env);
@@ -1563,9 +1573,12 @@ int mpsfm_ba_get_reduced_system(mpsfm_ba_handle* h, double* S, double* rhs, int3
     for (int C = 0; C < n; ++C) {
       const int br = R / 6, a = R % 6, bc = C / 6, b = C % 6;
       double v;
-      if (br < bc) v = Sb[ut_block(br, bc, h->ncv) * 36 + a * 6 + b];
-      else if (br > bc) v = Sb[ut_block(bc, br, h->ncv) * 36 + b * 6 + a];
-      else v = Sb[ut_block(br, br, h->ncv) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
+      const BlockSky sky{h->sky_first.data(), h->sky_start.data()};
+      const int lo = std::min(br, bc), hi = std::max(br, bc);
+      if (lo < sky.first[hi]) v = 0.0;
+      else if (br < bc) v = Sb[sky_block(sky, br, bc) * 36 + a * 6 + b];
+      else if (br > bc) v = Sb[sky_block(sky, bc, br) * 36 + b * 6 + a];
+      else v = Sb[sky_block(sky, br, br) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
       if (R == C) v += std::min(std::max(dU[R], o.min_lm_diagonal), o.max_lm_diagonal) / h->last_radius;
       if (S) S[(size_t)R * n + C] = v;
     }

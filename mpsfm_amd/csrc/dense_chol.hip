@@ -41,9 +41,11 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
         v = (R == C) ? 1.0 : 0.0;
       } else {
         const int br = R / 6, a = R - br * 6, bc = C / 6, b = C - bc * 6;
-        if (br < bc) v = P.Sblk[ut_block(br, bc, P.ncv) * 36 + a * 6 + b];
-        else if (br > bc) v = P.Sblk[ut_block(bc, br, P.ncv) * 36 + b * 6 + a];
-        else v = P.Sblk[ut_block(br, br, P.ncv) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
+        const int lo = br < bc ? br : bc, hi = br < bc ? bc : br;
+        if (lo < P.sky.first[hi]) v = 0.0;  // outside the block skyline: structurally zero
+        else if (br < bc) v = P.Sblk[sky_block(P.sky, br, bc) * 36 + a * 6 + b];
+        else if (br > bc) v = P.Sblk[sky_block(P.sky, bc, br) * 36 + b * 6 + a];
+        else v = P.Sblk[sky_block(P.sky, br, br) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
         if (R == C) v += fmin(fmax(P.diagU[R], P.min_diag), P.max_diag) / P.radius;
       }
     }
