@@ -73,11 +73,19 @@ def main():
 
     prob, _ = make_config(args.config, seed=0, shard=rank)
     opts = capi.default_options(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    collective = None
     if dist is not None:
-        from mpsfm_amd.dist import make_torch_allreduce
+        from mpsfm_amd.dist import hook_options, make_torch_allreduce, use_native_rccl
 
-        fn, keep = make_torch_allreduce()
-        opts.allreduce = fn
+        # default: the library's own RCCL communicator (no Python inside the LM loop); MPSFM_BENCH_COLLECTIVE=hook (or a
+        # non-RCCL rehearsal backend) goes through the torch.distributed hook
+        if backend == "nccl" and os.environ.get("MPSFM_BENCH_COLLECTIVE", "rccl") == "rccl":
+            use_native_rccl(opts)
+            collective = "native RCCL (ncclAllReduce on the solver's stream)"
+        else:
+            fn, keep = make_torch_allreduce()
+            hook_options(opts, fn)
+            collective = f"torch.distributed hook ({backend})"
 
     h = capi.BAHandle(prob, opts)
 
@@ -177,7 +185,7 @@ def main():
         "config": {
             "workload": f"{args.config}: {CONFIGS[args.config][0]} cameras, {CONFIGS[args.config][1]} landmarks per rank, "
                         f"{prob.n_obs} reprojection + {prob.n_dobs} log-depth blocks per rank, SoftL1/Cauchy, Ceres-default LM",
-            "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
+            "parallelism": (f"landmark-sharded x{world}, {collective}" if collective else f"landmark-sharded x{world}") if (world > 1 or collective) else "single GPU",
             "residual_blocks_total": last["num_residual_blocks"],
         },
         "solve": {

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MPSFM_ABI_VERSION 1
+#define MPSFM_ABI_VERSION 2
 
 /* ---- error codes -------------------------------------------------------------------- */
 #define MPSFM_OK 0
@@ -116,8 +116,17 @@ typedef struct mpsfm_ba_options {
   int32_t device;                           /* HIP device ordinal                      */
   void* stream;                             /* hipStream_t to run on, NULL = own stream */
   int32_t verbose;                          /* >0: per-iteration line on stderr         */
-  mpsfm_allreduce_fn allreduce;             /* NULL: single shard                       */
+  mpsfm_allreduce_fn allreduce;             /* NULL: single shard (or the native RCCL communicator below) */
   void* allreduce_user;
+  /* landmark sharding over the GPUs of a node: this rank's position ... */
+  int32_t world_size;                       /* 0 / 1: single shard; > 1 with the hook: lets the per-rank maxima (gradient
+                                               tolerance test) travel in per-rank slots of the summed buffer           */
+  int32_t rank;
+  /* ... and, with use_rccl = 1, the library's OWN communicator: ncclCommInitRank(world_size, comm_id, rank) at
+     mpsfm_ba_create, ncclAllReduce(sum, fp64) on the handle's stream for every exchange (no host callback per LM
+     iteration).  comm_id comes from mpsfm_comm_unique_id() on one rank; the caller hands it to the others. */
+  int32_t use_rccl;
+  uint8_t comm_id[128];
 } mpsfm_ba_options;
 
 #define MPSFM_MAX_TRACE 64
@@ -163,6 +172,8 @@ const char* mpsfm_last_error(void);
 /* number of visible gfx950 devices (0 on a CPU-only host; does not initialise a context) */
 int mpsfm_device_count(void);
 void mpsfm_ba_default_options(mpsfm_ba_options* opt);
+/* ncclGetUniqueId of the RCCL library found in the process (dlopen): 128 bytes for mpsfm_ba_options.comm_id */
+int mpsfm_comm_unique_id(uint8_t id[128]);
 
 /* -- bundle adjustment: replaces pyceres.solve(options, bundler.problem, summary)
  *    (bundle_adjustment.py:184, 285-293) ---------------------------------------------- */

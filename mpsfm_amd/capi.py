@@ -23,7 +23,7 @@ EXPORTS = [
     "mpsfm_ba_sweep_once", "mpsfm_ba_get_reduced_system", "mpsfm_ba_reduced_dim",
     "mpsfm_ba_get_dense_solution", "mpsfm_ba_dense_solve_once", "mpsfm_point_covs",
     "mpsfm_triangulate_tracks", "mpsfm_filter_tracks", "mpsfm_integrate_depth", "mpsfm_integrate_depth_batch",
-    "mpsfm_integration_variances", "mpsfm_depth_blocks",
+    "mpsfm_integration_variances", "mpsfm_depth_blocks", "mpsfm_comm_unique_id",
 ]
 
 _lib = None
@@ -86,6 +86,15 @@ def default_options(**kw) -> COptions:
     for k, v in kw.items():
         setattr(o, k, v)
     return o
+
+
+def comm_unique_id() -> bytes:
+    """128 bytes for COptions.comm_id (ncclGetUniqueId of the RCCL library in the process)."""
+    buf = (C.c_uint8 * 128)()
+    L = lib()
+    L.mpsfm_comm_unique_id.argtypes = [C.c_void_p]
+    _check(L.mpsfm_comm_unique_id(C.addressof(buf)))
+    return bytes(buf)
 
 
 def make_allreduce(fn):

@@ -954,6 +954,22 @@ __global__ __launch_bounds__(kThreads) void k_pts_sqnorm(int64_t np, const uint1
   if (threadIdx.x == 0) part[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+// Landmark-sharded runs: the tail of the reduced buffer is SUM-all-reduced, but the landmark gradient max-norm needs a MAX.
+// Before the exchange every rank moves its value into its own slot (the others stay zero); afterwards the maximum over
+// the slots is the global value.  Beyond kMaxRankSlots ranks the slot is shared (sum of maxima: conservative).
+__global__ void k_gmax_to_slot(double* redsc, int rank) {
+  if (threadIdx.x == 0) { redsc[SC_RANK0 + (rank % kMaxRankSlots)] = redsc[SC_GMAX_PTS]; redsc[SC_GMAX_PTS] = 0.0; }
+}
+__global__ void k_gmax_from_slots(const double* redsc, double* scal) {
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+    for (int r = 0; r < kMaxRankSlots; ++r) m = fmax(m, redsc[SC_RANK0 + r]);
+    scal[U_X_COST] = redsc[SC_COST]; scal[U_X_BAD] = redsc[SC_BAD]; scal[U_GMAX_PTS] = m;
+  }
+}
+void launch_gmax_to_slot(double* redsc, int rank, hipStream_t s) { hipLaunchKernelGGL(k_gmax_to_slot, dim3(1), dim3(64), 0, s, redsc, rank); }
+void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t s) { hipLaunchKernelGGL(k_gmax_from_slots, dim3(1), dim3(64), 0, s, redsc, scal); }
+
 // ---- launch wrappers ------------------------------------------------------------------------------
 void init_tile_tables(hipStream_t) {}
 

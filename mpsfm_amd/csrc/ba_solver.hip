@@ -18,6 +18,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include <dlfcn.h>
 #include <sched.h>
 
 #include "common.h"
@@ -39,6 +40,8 @@ void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const d
                        const double* gc, double* q2, double* t2, double* scal, hipStream_t, const double* intr = nullptr,
                        const int32_t* intr_idx = nullptr, double* camtab2 = nullptr, int* chol_fail = nullptr);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
+void launch_gmax_to_slot(double* redsc, int rank, hipStream_t);
+void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
 void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const DenseEnvelope* env);
 size_t dense_work_doubles(int nt);
@@ -180,6 +183,39 @@ static void release_pinned(void* p) {
   R.pinned[R.dev()].push_back(p);
 }
 
+// ---- RCCL, loaded at run time (no link-time dependency: single-GPU users never touch it) -----------------------------
+// The four entry points the landmark-sharded solve needs.  dlopen finds the library already in the process (torch
+// ships one) or the system's /opt/rocm copy.
+namespace {
+struct Rccl {
+  typedef struct { char internal[128]; } UniqueId;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  std::string why;
+  Rccl() {
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) { why = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+    GetUniqueId = (int (*)(UniqueId*))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (int (*)(void**, int, UniqueId, int))dlsym(lib, "ncclCommInitRank");
+    AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+    CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    ok = GetUniqueId && CommInitRank && AllReduce && CommDestroy;
+    if (!ok) why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+  }
+};
+Rccl& rccl() { static Rccl* r = new Rccl(); return *r; }
+constexpr int kNcclDouble = 8, kNcclSum = 0;  // ncclFloat64, ncclSum (rccl.h)
+}  // namespace
+
 template <typename T>
 static int dev_alloc(T** p, size_t count) {
   if (count == 0) count = 1;
@@ -312,6 +348,7 @@ using namespace mpsfm;
 struct mpsfm_ba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
+  void* comm = nullptr;  // ncclComm_t of a landmark-sharded run with use_rccl
   DenseOverlap ov;  // second stream for the dense factorisation in outer panels (MPSFM_CHOL_NB)
   DenseEnvelope env;  // block skyline of the reduced system
   std::vector<int32_t> env_rows_start, env_prow_start, env_rows;
@@ -379,6 +416,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
                   h->d_env_first, h->d_env_rows, h->d_env_prow, h->d_sky_first, h->d_sky_start};
   for (void* p : ptrs) cached_free(p);
+  if (h->comm) (void)rccl().CommDestroy(h->comm);
   release_pinned(h->h_scal);
   for (auto& e : h->ev) release_event(e, true);
   for (auto& e : h->ov.evF) release_event(e, false);
@@ -411,12 +449,32 @@ static int check_problem(const mpsfm_ba_problem* P) {
   return 0;
 }
 
+static bool sharded(const mpsfm_ba_handle* h) { return h->opt.allreduce != nullptr || h->comm != nullptr; }
+static int rccl_allreduce(mpsfm_ba_handle* h, double* dbuf, int64_t count) {
+  const int rc = rccl().AllReduce(dbuf, dbuf, (size_t)count, kNcclDouble, kNcclSum, h->comm, h->stream);
+  if (rc != 0) return fail(MPSFM_ECOMM, std::string("ncclAllReduce: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "failed"));
+  return 0;
+}
 static int allreduce_host(mpsfm_ba_handle* h, double* buf, int64_t count) {
+  if (count <= 0) return 0;
+  if (h->comm) {  // host values travel through a device scratch block
+    double* d = (double*)cached_malloc(sizeof(double) * (size_t)count);
+    if (!d) return fail(MPSFM_ENOMEM, "hipMalloc failed");
+    int rc = 0;
+    if (hipMemcpyAsync(d, buf, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail(MPSFM_EHIP, "hipMemcpyAsync failed");
+    if (!rc) rc = rccl_allreduce(h, d, count);
+    if (!rc && hipMemcpyAsync(buf, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(MPSFM_EHIP, "hipMemcpyAsync failed");
+    (void)hipStreamSynchronize(h->stream);
+    cached_free(d);
+    return rc;
+  }
   if (!h->opt.allreduce) return 0;
   if (h->opt.allreduce(h->opt.allreduce_user, buf, count, 0, nullptr)) return fail(MPSFM_ECOMM, "all-reduce hook failed (host buffer)");
   return 0;
 }
 static int allreduce_dev(mpsfm_ba_handle* h, double* buf, int64_t count) {
+  if (count <= 0) return 0;
+  if (h->comm) return rccl_allreduce(h, buf, count);
   if (!h->opt.allreduce) return 0;
   if (h->opt.allreduce(h->opt.allreduce_user, buf, count, 1, (void*)h->stream)) return fail(MPSFM_ECOMM, "all-reduce hook failed (device buffer)");
   return 0;
@@ -931,7 +989,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     }
     const char* envs = std::getenv("MPSFM_CHOL_ENVELOPE");
     if (envs && std::atoi(envs) == 0) std::fill(first_blk.begin(), first_blk.end(), 0);  // A/B: treat S as dense
-    if (h->opt.allreduce && ncv > 0) {
+    if (sharded(h) && ncv > 0) {
       // landmark shards see different camera pairs: every rank needs the UNION.  The hook only sums, so the minimum over
       // ranks is found by bisection on indicator sums (the same number of rounds on every rank).
       std::vector<double> lo((size_t)ncv, 0.0), hi((size_t)ncv), ind((size_t)ncv);
@@ -1167,7 +1225,8 @@ static int run_track_sweep(mpsfm_ba_handle* h, double radius) {
   SweepArgs a = sweep_args(h, radius);
   launch_track_sweep(a, h->nchunks, false, s);
   if (h->nchunks + h->nlong > 0)
-    launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, h->opt.allreduce ? nullptr : h->d_scal + U_X_COST);
+    launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, sharded(h) ? nullptr : h->d_scal + U_X_COST);
+  if (sharded(h)) launch_gmax_to_slot(h->d_redsc, h->opt.rank > 0 ? h->opt.rank : 0, s);
   h->last_radius = radius;
   return 0;
 }
@@ -1272,8 +1331,8 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
       if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part2, h->nchunks + h->nlong, 8, 5, 0u, h->d_scal, s);
     }
     if (int rc = allreduce_dev(h, h->d_scal, 5)) return rc;
-    if (h->opt.allreduce)  // the all-reduced scalars of the track sweep (single rank: written by its reduction directly)
-      HIP_TRY(hipMemcpyAsync(h->d_scal + U_X_COST, h->d_redsc, sizeof(double) * 3, hipMemcpyDeviceToDevice, s));
+    if (sharded(h))  // the all-reduced scalars of the track sweep (single rank: written by its reduction directly): cost and
+      launch_gmax_from_slots(h->d_redsc, h->d_scal, s);  // bad count summed, landmark-gradient maximum over the rank slots
     HIP_TRY(hipEventRecord(h->ev[3], s));
     HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * U_COUNT, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1397,6 +1456,16 @@ static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, cons
     if (pooled_stream(&h->stream) != hipSuccess) { delete h; return fail(MPSFM_EHIP, "hipStreamCreate failed"); }
     h->own_stream = true;
   }
+  if (o->use_rccl && o->world_size >= 1) {
+    Rccl& R = rccl();
+    if (!R.ok) { free_handle(h); return fail(MPSFM_ECOMM, "use_rccl: " + R.why); }
+    if (o->rank < 0 || o->rank >= o->world_size) { free_handle(h); return fail(MPSFM_EINVAL, "rank out of range"); }
+    Rccl::UniqueId id;
+    std::memcpy(id.internal, o->comm_id, sizeof(id.internal));
+    const int nrc = R.CommInitRank(&h->comm, o->world_size, id, o->rank);
+    if (nrc != 0) { h->comm = nullptr; free_handle(h); return fail(MPSFM_ECOMM, std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(nrc) : "failed")); }
+    since("ncclCommInitRank");
+  }
   int rc = build(h, P, st);
   since("build");
   if (rc == 0 && st) rc = upload_state(h, st, true);
@@ -1423,6 +1492,17 @@ int mpsfm_device_count(void) {
     if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++good;
   }
   return good;
+}
+
+int mpsfm_comm_unique_id(uint8_t id[128]) {
+  if (!id) return fail(MPSFM_EINVAL, "id is NULL");
+  Rccl& R = rccl();
+  if (!R.ok) return fail(MPSFM_ECOMM, R.why);
+  Rccl::UniqueId u;
+  const int rc = R.GetUniqueId(&u);
+  if (rc != 0) return fail(MPSFM_ECOMM, std::string("ncclGetUniqueId: ") + (R.GetErrorString ? R.GetErrorString(rc) : "failed"));
+  std::memcpy(id, u.internal, 128);
+  return 0;
 }
 
 void mpsfm_ba_default_options(mpsfm_ba_options* o) {

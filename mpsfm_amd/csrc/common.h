@@ -75,7 +75,8 @@ struct LossParams {
 };
 
 // scalar slots of the reduced buffer tail (all-reduced with S)
-enum { SC_COST = 0, SC_BAD = 1, SC_GMAX_PTS = 2, SC_COUNT = 8 };
+constexpr int kMaxRankSlots = 64;  // ranks whose landmark-gradient maxima travel exactly (one slot each in the summed tail)
+enum { SC_COST = 0, SC_BAD = 1, SC_GMAX_PTS = 2, SC_RANK0 = 8, SC_COUNT = 8 + kMaxRankSlots };
 
 // scalar slots produced by the update sweep + camera update (host reads these each iteration)
 enum {

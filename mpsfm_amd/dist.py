@@ -106,3 +106,37 @@ def make_torch_allreduce(group=None):
 
     fn = ALLREDUCE_FN(_cb)
     return fn, (_cb, fn)
+
+
+def hook_options(opts, fn, group=None):
+    """`opts` for a sharded solve through the hook: the hook itself plus this rank's position (per-rank slots of the
+    summed scalar tail keep the landmark-gradient maximum exact)."""
+    import torch.distributed as dist
+
+    opts.allreduce = fn
+    opts.world_size, opts.rank = dist.get_world_size(group), dist.get_rank(group)
+    return opts
+
+
+def use_native_rccl(opts, group=None):
+    """Fills `opts` (capi.COptions) so that the library creates its OWN RCCL communicator over the ranks of `group`
+    (ncclCommInitRank at mpsfm_ba_create): rank 0 draws the unique id, torch.distributed only carries its 128 bytes to
+    the other ranks.  Afterwards no Python runs inside the LM loop: every exchange is an ncclAllReduce on the solver's
+    stream."""
+    import torch
+    import torch.distributed as dist
+
+    from . import capi
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(t, src=0, group=group)
+    raw = bytes(t.cpu().numpy().tobytes())
+    for i in range(128):
+        opts.comm_id[i] = raw[i]
+    opts.world_size, opts.rank, opts.use_rccl = world, rank, 1
+    opts.allreduce = ALLREDUCE_FN()  # NULL: the hook is not used
+    return opts

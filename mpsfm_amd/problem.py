@@ -81,6 +81,10 @@ class COptions(C.Structure):
         ("verbose", C.c_int32),
         ("allreduce", ALLREDUCE_FN),
         ("allreduce_user", C.c_void_p),
+        ("world_size", C.c_int32),
+        ("rank", C.c_int32),
+        ("use_rccl", C.c_int32),
+        ("comm_id", C.c_uint8 * 128),
     ]
 
 

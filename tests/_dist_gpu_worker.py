@@ -35,6 +35,7 @@ def main():
         fn, keep = make_torch_allreduce()
         opts = capi.default_options(device=0, verbose=int(os.environ.get("MPSFM_VERBOSE", "0")))  # stream 0: the library creates its own, the hook must follow it
         opts.allreduce = fn
+        opts.world_size, opts.rank = world, rank  # exact landmark-gradient maximum through the per-rank slots
         s = capi.ba_solve(shard, opts)
         res.update(lo=lo, hi=hi, final_cost=s["final_cost"], initial_cost=s["initial_cost"], iters=s["num_iterations"],
                    nblocks=s["num_residual_blocks"], trace=list(s["trace_cost"]))

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/mpsfm_hip.h but not exported"
     assert set(capi.EXPORTS) <= declared
-    assert L.mpsfm_abi_version() == 1
+    assert L.mpsfm_abi_version() == 2
 
 
 def test_triangulator_and_gather_entry_points_check_arguments_first():

@@ -315,16 +315,19 @@ def test_max_iterations_and_tight_tolerances():
         assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
 
 
-def test_rccl_hook_single_rank():
-    """bench.py with a one-rank NCCL(RCCL) process group: the device-buffer all-reduce hook, the
-    zero-copy tensor view and the shared stream are exercised end to end."""
+@pytest.mark.parametrize("collective", ["rccl", "hook"])
+def test_rccl_single_rank(collective):
+    """bench.py with a one-rank NCCL(RCCL) process group.  "rccl": the library's own communicator (ncclCommInitRank from a
+    unique id, ncclAllReduce on the solver's stream, no Python in the LM loop); "hook": the torch.distributed hook with
+    the zero-copy tensor view and the shared stream.  Same result as the plain single-GPU solve."""
     import json
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MPSFM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, MPSFM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MPSFM_BENCH_COLLECTIVE=collective)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C2", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--kernel-reps", "2"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -333,6 +336,7 @@ def test_rccl_hook_single_rank():
     s = capi.ba_solve(ref)
     assert d["solve"]["final_cost"] == pytest.approx(s["final_cost"], rel=1e-9)
     assert d["solve"]["lm_iterations"] == s["num_iterations"]
+    assert ("native RCCL" if collective == "rccl" else "hook") in d["config"]["parallelism"]
 
 
 @pytest.mark.timeout(600)
