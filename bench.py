@@ -129,13 +129,15 @@ def main():
     }
     roof_sweep["frac"] = roof_sweep["achieved"] / roof_sweep["peak"]
     roof_dense = {
-        "kernel": "k_chol_step+k_inv (reduced camera system: tiled Cholesky with inverse propagation)", "bound": "mfma", "achieved": flops_dense / (dense_ms * 1e-3) / 1e12,
+        "kernel": "k_chol_step (+k_assemble, k_inv_*): reduced camera system, tiled block-skyline Cholesky", "bound": "mfma", "achieved": flops_dense / (dense_ms * 1e-3) / 1e12,
         "peak": 78.6, "unit": "TFLOP/s", "traffic": None, "algorithmic_flops": flops_dense, "avg_ms": dense_ms, "n": n,
         # one dense solve = this many launches; avg_ms is the HIP-event time of the whole sequence, to be compared with
         # sum(launches x rocprofv3 AverageNs) from profiles/rNN_kernel_stats.csv
         "launches_per_solve": ({"k_assemble": 1, "k_chol_step": (n + 31) // 32, "k_inv_w": 1, "k_inv_y": 1} if (n + 31) // 32 <= 64 else
-                               {"k_assemble": 1, "k_chol_step": (n + 31) // 32, "k_big_update": ((n + 31) // 32 + 7) // 8 * 2,
-                                "k_z_init": 1, "k_backsub_group": ((n + 31) // 32 + 3) // 4}),
+                               {"k_assemble": 1, "k_chol_step": (n + 31) // 32, "k_z_init": 1, "k_backsub_group": ((n + 31) // 32 + 3) // 4}),
+        # the factorisation works inside the block skyline of S (tiles that can be nonzero): the flops actually issued
+        # are fewer than the dense count `algorithmic_flops` (n^3/3 + 2 n^2) that `achieved` is quoted on
+        "note": "achieved = dense-equivalent flops / time; the skyline factorisation skips structurally zero tiles",
     }
     roof_dense["frac"] = roof_dense["achieved"] / roof_dense["peak"]
     t_lin, t_den, t_upd = last["time_linearize_s"], last["time_dense_s"], last["time_update_s"]

@@ -36,8 +36,10 @@ def main():
         opts = capi.default_options(device=0, verbose=int(os.environ.get("MPSFM_VERBOSE", "0")))  # stream 0: the library creates its own, the hook must follow it
         opts.allreduce = fn
         opts.world_size, opts.rank = world, rank  # exact landmark-gradient maximum through the per-rank slots
+        if os.environ.get("MPSFM_TEST_GTOL"):
+            opts.gradient_tolerance = float(os.environ["MPSFM_TEST_GTOL"])
         s = capi.ba_solve(shard, opts)
-        res.update(lo=lo, hi=hi, final_cost=s["final_cost"], initial_cost=s["initial_cost"], iters=s["num_iterations"],
+        res.update(lo=lo, hi=hi, final_cost=s["final_cost"], initial_cost=s["initial_cost"], iters=s["num_iterations"], termination=s["termination"],
                    nblocks=s["num_residual_blocks"], trace=list(s["trace_cost"]))
         np.savez(os.path.join(out, f"state{rank}.npz"), pts=shard.pts, cam_quat=shard.cam_quat, cam_t=shard.cam_t)
     with open(os.path.join(out, f"r{rank}.json"), "w") as f:

@@ -340,11 +340,14 @@ def test_rccl_single_rank(collective):
 
 
 @pytest.mark.timeout(600)
-def test_two_process_sharded_solve_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("gtol", [None, 5.0e3])
+def test_two_process_sharded_solve_on_one_gpu(tmp_path, gtol):
     """Two OS processes, one landmark shard each, both on cuda:0; the reduced system is summed across them on
     the DEVICE buffers through mpsfm_amd.dist.make_torch_allreduce (gloo here: RCCL does not allow two ranks
     on one GPU).  The library runs on a stream of its own, so this fails if the hook does not order the
-    collective with that stream.  Must reproduce the single-process trajectory."""
+    collective with that stream.  Must reproduce the single-process trajectory — also when the solve ends on the
+    gradient tolerance (gtol case): the landmark-gradient maximum is a MAX over ranks inside a SUM all-reduce (per-rank
+    slots), a sum of the per-rank maxima would stop later than the single-process solve."""
     import json
     import os
     import socket
@@ -358,7 +361,8 @@ def test_two_process_sharded_solve_on_one_gpu(tmp_path):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_gpu_worker.py")
     procs = []
     for r in range(world):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), OMP_NUM_THREADS="2",
+                   MPSFM_TEST_GTOL="" if gtol is None else repr(gtol))
         procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), str(seed)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=500) for p in procs]
@@ -368,8 +372,12 @@ def test_two_process_sharded_solve_on_one_gpu(tmp_path):
     if not all(r["supported"] for r in res):
         pytest.skip("this torch build cannot all-reduce device tensors with gloo")
     ref, _ = make_scene(12, 6000, True, seed=seed)
-    s = capi.ba_solve(ref)
+    s = capi.ba_solve(ref, capi.default_options(**({} if gtol is None else {"gradient_tolerance": gtol})))
+    assert s["termination"] == ("function_tolerance" if gtol is None else "gradient_tolerance")
+    if gtol is not None:
+        assert 2 <= s["num_iterations"] < 12
     for r, o in enumerate(res):
+        assert o["termination"] == s["termination"]
         assert o["iters"] == s["num_iterations"] and o["nblocks"] == s["num_residual_blocks"]
         assert o["initial_cost"] == pytest.approx(s["initial_cost"], rel=1e-12)
         assert o["final_cost"] == pytest.approx(s["final_cost"], rel=1e-9)
