@@ -202,24 +202,22 @@ __device__ __forceinline__ void stacked_panel(double (&a)[kTile], int lane, doub
     __builtin_amdgcn_wave_barrier();
     // rank-kSP update of the next panel's columns (its chain starts on them): all reads first, two batches
     {
-      // 4 reads per column of L; at most 15 LDS operations can be in flight, so two halves of 16 reads
-      v2d m[kSP][kSP / 2];
+      // 4 reads per column of L; two halves of 16 reads (at most 15 LDS operations are in flight, and 32 rows at once
+      // would push the wave past its 256 registers)
 #pragma unroll
-      for (int k = 0; k < kSP; ++k) {
-        if (k == kSP / 2) {
+      for (int half = 0; half < 2; ++half) {
+        v2d m[kSP / 2][kSP / 2];
 #pragma unroll
-          for (int kk = 0; kk < kSP / 2; ++kk) lds_wait(m[kk]);
-        }
-        lds_row_load<kSP / 2>(lds_addr(s_P + k * kTile + J0 + kSP), m[k]);
-      }
+        for (int k = 0; k < kSP / 2; ++k) lds_row_load<kSP / 2>(lds_addr(s_P + (half * (kSP / 2) + k) * kTile + J0 + kSP), m[k]);
 #pragma unroll
-      for (int kk = kSP / 2; kk < kSP; ++kk) lds_wait(m[kk]);
+        for (int k = 0; k < kSP / 2; ++k) lds_wait(m[k]);
 #pragma unroll
-      for (int k = 0; k < kSP; ++k) {
+        for (int k = 0; k < kSP / 2; ++k) {
 #pragma unroll
-        for (int q = 0; q < kSP / 2; ++q) {
-          a[J0 + kSP + 2 * q] = __builtin_fma(-a[J0 + k], m[k][q].x, a[J0 + kSP + 2 * q]);
-          a[J0 + kSP + 2 * q + 1] = __builtin_fma(-a[J0 + k], m[k][q].y, a[J0 + kSP + 2 * q + 1]);
+          for (int q = 0; q < kSP / 2; ++q) {
+            a[J0 + kSP + 2 * q] = __builtin_fma(-a[J0 + half * (kSP / 2) + k], m[k][q].x, a[J0 + kSP + 2 * q]);
+            a[J0 + kSP + 2 * q + 1] = __builtin_fma(-a[J0 + half * (kSP / 2) + k], m[k][q].y, a[J0 + kSP + 2 * q + 1]);
+          }
         }
       }
     }
