@@ -45,7 +45,7 @@ void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
 void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const DenseEnvelope* env);
 size_t dense_work_doubles(int nt);
-double* dense_pinv(double* work, int nt, const DenseOverlap* ov);
+double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const DenseEnvelope* env);
 
 thread_local std::string g_err;
 extern int g_dbg_flags;  // dense_chol.hip: bits 0-7 dense-solve ablations, bits 8-15 track-sweep ablations
@@ -353,6 +353,10 @@ struct mpsfm_ba_handle {
   DenseEnvelope env;  // block skyline of the reduced system
   std::vector<int32_t> env_rows_start, env_prow_start, env_rows;
   int32_t *d_env_first = nullptr, *d_env_rows = nullptr, *d_env_prow = nullptr;
+  int32_t *d_env_items = nullptr, *d_env_flags = nullptr;  // fused factorisation: item table, hand-off flags
+  uint32_t* d_env_ticket = nullptr;
+  uint32_t env_ticket_base = 0;
+  int32_t env_epoch = 0;
   std::vector<int32_t> sky_first;   // block skyline of S (BlockSky), host copies
   std::vector<int64_t> sky_start;
   int32_t* d_sky_first = nullptr;
@@ -414,7 +418,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
-                  h->d_env_first, h->d_env_rows, h->d_env_prow, h->d_sky_first, h->d_sky_start};
+                  h->d_env_first, h->d_env_rows, h->d_env_prow, h->d_sky_first, h->d_sky_start, h->d_env_items, h->d_env_flags, h->d_env_ticket};
   for (void* p : ptrs) cached_free(p);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
   release_pinned(h->h_scal);
@@ -1039,6 +1043,29 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     h->env.valid = nt >= 1;
     h->env.d_first = h->d_env_first; h->env.d_rows = h->d_env_rows; h->env.d_prow = h->d_env_prow;
     h->env.h_rows_start = h->env_rows_start.data(); h->env.h_prow_start = h->env_prow_start.data(); h->env.h_rows = h->env_rows.data();
+    // fused factorisation: one work item per tile of the skyline (rows k..nt of column k), taken by the workgroups in
+    // this order.  An item only waits for items in front of it: the tile (k+1,k) that also publishes the updated
+    // diagonal tile D(k+1) comes first in its column, the diagonal item (it only inverts L(k,k)) last.
+    {
+      const char* fe = std::getenv("MPSFM_CHOL_FUSED");
+      if (!(fe && std::atoi(fe) == 0) && nt >= 1) {
+        std::vector<int32_t> items;
+        for (int k = 0; k < nt; ++k) {
+          for (int ti = k + 1; ti <= nt; ++ti) if (first[(size_t)ti] <= k) { items.push_back(ti); items.push_back(k); }
+          items.push_back(k); items.push_back(k);
+        }
+        const size_t nflags = ((size_t)(nt + 1) * (size_t)(nt + 2) / 2 + (size_t)nt + 1) * kFusedFlagStride;
+        if ((rc2 = dev_upload(&h->d_env_items, items))) return rc2;
+        if ((rc2 = dev_alloc(&h->d_env_flags, nflags))) return rc2;
+        if ((rc2 = dev_alloc(&h->d_env_ticket, 1))) return rc2;
+        HIP_TRY(hipMemset(h->d_env_flags, 0, sizeof(int32_t) * nflags));
+        HIP_TRY(hipMemset(h->d_env_ticket, 0, sizeof(uint32_t)));
+        h->env_ticket_base = 0; h->env_epoch = 0;
+        h->env.d_items = h->d_env_items; h->env.n_items = (int32_t)(items.size() / 2);
+        h->env.d_flags = h->d_env_flags; h->env.d_ticket = h->d_env_ticket;
+        h->env.h_ticket_base = &h->env_ticket_base; h->env.h_epoch = &h->env_epoch;
+      }
+    }
     if (h->opt.verbose >= 2) {
       int64_t inside = 0;
       for (int ti = 0; ti < nt; ++ti) inside += ti - first[(size_t)ti] + 1;
@@ -1236,7 +1263,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
   // d_fail is zero here: cleared at creation and re-armed by k_cam_update after every read
   if (h->n > 0) {
     AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
-                    h->opt.max_lm_diagonal, h->d_A, dense_pinv(h->d_dwork, h->nt, &h->ov)};
+                    h->opt.max_lm_diagonal, h->d_A, dense_pinv(h->d_dwork, h->nt, &h->ov, &h->env)};
     launch_assemble(as, s);
     launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->env);
   }
@@ -1342,7 +1369,9 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); sum->time_update_s += 1e-3 * ms;
     ++n_jac_evals; ++n_cost_evals;
     const double* sc = h->h_scal;
-    const int h_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;  // set by k_chol_step, published by k_cam_update
+    const int h_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;  // set by the factorisation, published by k_cam_update
+    if (sc[U_CHOL_FAIL] == 2.0)  // a workgroup of k_chol_fused gave up waiting for a tile (its polls are bounded): never a valid step
+      return finish(fail(MPSFM_EHIP, "fused Cholesky: a hand-off between workgroups did not arrive within the poll bound (set MPSFM_CHOL_FUSED=0 to use the per-step path)"));
 
     // ---- decisions (Ceres trust_region_minimizer.cc order) ------------------------------------
     x_cost = sc[U_X_COST];

@@ -272,6 +272,7 @@ struct DenseOverlap {
 // nonzero in S and in its Cholesky factor only for tj >= first[ti].  Per factorisation step j the rows that take part:
 //   rows(j)  = { ti > j : first[ti] <= j }  (L(ti, j) != 0; always ends with the right-hand-side row nt)
 //   prow(j)  = { ti >= j+1 : first[ti] <= j+1 }  (tiles of the panel column j+1 inside the skyline), j = -1 .. nt-2
+constexpr int kFusedFlagStride = 32;  // int32 per hand-off flag of k_chol_fused: one 128-byte line each
 struct DenseEnvelope {
   bool valid = false;
   const int32_t* d_first = nullptr;  // [nt+1]
@@ -280,6 +281,13 @@ struct DenseEnvelope {
   const int32_t* h_rows_start = nullptr;  // host: [nt]   offsets of rows(j)   (entry nt-1 = total)
   const int32_t* h_prow_start = nullptr;  // host: [nt+1] offsets of prow(j-1) (entry nt = total)
   const int32_t* h_rows = nullptr;        // host copy of the row lists (the launcher looks at rows(j)[0])
+  // fused factorisation (k_chol_fused: ONE launch, one workgroup per skyline tile, hand-offs by flags); d_items == NULL: off
+  const int32_t* d_items = nullptr;   // [n_items][2] = (ti, tk), in the order workgroups take them (a topological order)
+  int32_t n_items = 0;
+  int32_t* d_flags = nullptr;         // kFusedFlagStride x ([(nt+1)(nt+2)/2] epoch at which L(ti,tk) was stored | [nt+1] epoch of the updated D(k))
+  uint32_t* d_ticket = nullptr;       // running ticket counter (never reset: the host keeps the base of every launch)
+  uint32_t* h_ticket_base = nullptr;  // host: tickets handed out by earlier launches
+  int32_t* h_epoch = nullptr;         // host: epoch of the last launch
 };
 
 struct AssembleArgs {
