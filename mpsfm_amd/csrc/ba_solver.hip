@@ -1048,7 +1048,10 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     // diagonal tile D(k+1) comes first in its column, the diagonal item (it only inverts L(k,k)) last.
     {
       const char* fe = std::getenv("MPSFM_CHOL_FUSED");
-      if (!(fe && std::atoi(fe) == 0) && nt >= 1) {
+      // off unless MPSFM_CHOL_FUSED=1: measured SLOWER than the per-step launches (C3: 0.69 vs 0.38 ms per solve — a tile
+      // handed between workgroups costs 2.8 us flag-to-flag plus 4-7 us until the consumer holds it, against 3.3 + 1.5 us
+      // for a launch boundary and a cold load); kept for A/B
+      if (fe && std::atoi(fe) == 1 && nt >= 1) {
         std::vector<int32_t> items;
         for (int k = 0; k < nt; ++k) {
           for (int ti = k + 1; ti <= nt; ++ti) if (first[(size_t)ti] <= k) { items.push_back(ti); items.push_back(k); }
@@ -1371,7 +1374,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     const double* sc = h->h_scal;
     const int h_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;  // set by the factorisation, published by k_cam_update
     if (sc[U_CHOL_FAIL] == 2.0)  // a workgroup of k_chol_fused gave up waiting for a tile (its polls are bounded): never a valid step
-      return finish(fail(MPSFM_EHIP, "fused Cholesky: a hand-off between workgroups did not arrive within the poll bound (set MPSFM_CHOL_FUSED=0 to use the per-step path)"));
+      return finish(fail(MPSFM_EHIP, "fused Cholesky: a hand-off between workgroups did not arrive within the poll bound (unset MPSFM_CHOL_FUSED to use the per-step path)"));
 
     // ---- decisions (Ceres trust_region_minimizer.cc order) ------------------------------------
     x_cost = sc[U_X_COST];
