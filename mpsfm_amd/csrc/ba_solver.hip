@@ -43,9 +43,12 @@ void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, dou
 void launch_gmax_to_slot(double* redsc, int rank, hipStream_t);
 void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const DenseEnvelope* env);
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const DenseEnvelope* env, const LevelPlanDev* lp);
+bool dense_level(const DenseOverlap* ov, const LevelPlanDev* lp);
+int dense_plain_max_tiles();
+int dense_inv_rows();
 size_t dense_work_doubles(int nt);
-double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const DenseEnvelope* env);
+double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const DenseEnvelope* env, const LevelPlanDev* lp);
 
 thread_local std::string g_err;
 extern int g_dbg_flags;  // dense_chol.hip: bits 0-7 dense-solve ablations, bits 8-15 track-sweep ablations
@@ -353,14 +356,18 @@ struct mpsfm_ba_handle {
   DenseEnvelope env;  // block skyline of the reduced system
   std::vector<int32_t> env_rows_start, env_prow_start, env_rows;
   int32_t *d_env_first = nullptr, *d_env_rows = nullptr, *d_env_prow = nullptr;
-  int32_t *d_env_items = nullptr, *d_env_flags = nullptr;  // fused factorisation: item table, hand-off flags
-  uint32_t* d_env_ticket = nullptr;
-  uint32_t env_ticket_base = 0;
-  int32_t env_epoch = 0;
   std::vector<int32_t> sky_first;   // block skyline of S (BlockSky), host copies
   std::vector<int64_t> sky_start;
   int32_t* d_sky_first = nullptr;
   int64_t* d_sky_start = nullptr;
+  std::vector<int32_t> sky_index;   // index form of BlockSky (up to kIndexMaxSlots slots), host copy
+  int32_t* d_sky_index = nullptr;
+  CholPlan plan;                    // camera order, tile elimination tree and launch tables of the dense factorisation (chol_plan.h)
+  LevelPlanDev lp;
+  CholItem* d_lp_items = nullptr;
+  int32_t *d_lp_srcs = nullptr, *d_lp_rows = nullptr, *d_lp_struct_start = nullptr, *d_lp_struct_rows = nullptr, *d_lp_back_cols = nullptr, *d_lp_asm = nullptr;
+  std::vector<int32_t> nat_slot;    // variable camera in the caller's order -> slot (the accessors of S and y speak the caller's order)
+  int n_user = 0;                   // 6 x variable cameras: the reduced dimension the caller sees (n also counts dummy slots)
   bool own_stream = false;
   mpsfm_ba_options opt{};
   LossParams loss{};
@@ -372,7 +379,7 @@ struct mpsfm_ba_handle {
   int ncv = 0, n = 0, nt = 0, nchunks = 0, nlong = 0;
   LongHdr* d_lhdr = nullptr;
   double* d_wl = nullptr;
-  int64_t red_count = 0, sblk_count = 0;
+  int64_t red_count = 0, sblk_count = 0, sblk_blocks = 0;
   std::vector<int32_t> perm;        // re-ordered landmark -> caller's index
   std::vector<int32_t> cam_slot_h;
   // device state
@@ -418,7 +425,8 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
-                  h->d_env_first, h->d_env_rows, h->d_env_prow, h->d_sky_first, h->d_sky_start, h->d_env_items, h->d_env_flags, h->d_env_ticket};
+                  h->d_env_first, h->d_env_rows, h->d_env_prow, h->d_sky_first, h->d_sky_start, h->d_sky_index,
+                  h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm};
   for (void* p : ptrs) cached_free(p);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
   release_pinned(h->h_scal);
@@ -549,9 +557,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     for (int k = 0; k < 6; ++k) cmask[(size_t)i * 6 + k] = 1.0;
     if (i == P->gauge_axis_cam) cmask[(size_t)i * 6 + 3] = 0.0;
   }
+  const int ncv_real = h->ncv;
+  h->n_user = 6 * ncv_real;
   h->n = 6 * h->ncv;
   h->nt = (h->n + 31) / 32;
-  const std::vector<int32_t>& slot = h->cam_slot_h;
+  std::vector<int32_t>& slot = h->cam_slot_h;  // the caller's order for now; re-assigned below from the camera graph
 
   // -- residual blocks grouped by landmark and merged into records.  Every host thread owns a contiguous
   //    landmark range: it scans the block lists for its landmarks (counting sort), orders each landmark's
@@ -661,6 +671,84 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   h->nblocks_total = P->n_obs + P->n_dobs;
 
   lap("merge records");
+  // -- camera order.  Up to kIndexMaxSlots variable cameras: the camera graph (who shares a variable landmark with whom,
+  //    summed over the ranks) decides the slot order — nested dissection when it shortens the dependent chain of the tile
+  //    factorisation (chol_plan.h) — and which 6x6 blocks of S exist.  Beyond: the caller's order and a block skyline.
+  const bool use_graph = ncv_real > 0 && ncv_real <= kIndexMaxSlots && !(std::getenv("MPSFM_CHOL_GRAPH") && std::atoi(std::getenv("MPSFM_CHOL_GRAPH")) == 0);
+  CamGraph graph;
+  if (use_graph) {
+    graph.init(ncv_real);
+    const int gparts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)recs.size() / 65536));
+    std::vector<std::vector<uint64_t>> gb((size_t)gparts);
+    run_parts(gparts, [&](int t, int nparts) {
+      std::vector<uint64_t>& B = gb[(size_t)t];
+      B.assign(graph.bits.size(), 0);
+      std::vector<int32_t> sl;
+      for (int p = (int)((int64_t)npu * t / nparts); p < (int)((int64_t)npu * (t + 1) / nparts); ++p) {
+        if (P->pt_const[p]) continue;
+        sl.clear();
+        for (int64_t r = prec[p]; r < prec[p + 1]; ++r) if (recs[r].slot >= 0 && (sl.empty() || sl.back() != recs[r].slot)) sl.push_back(recs[r].slot);
+        for (size_t a = 0; a < sl.size(); ++a)
+          for (size_t b = a + 1; b < sl.size(); ++b) {
+            B[(size_t)sl[a] * graph.words + (sl[b] >> 6)] |= 1ull << (sl[b] & 63);
+            B[(size_t)sl[b] * graph.words + (sl[a] >> 6)] |= 1ull << (sl[a] & 63);
+          }
+      }
+    });
+    for (const auto& B : gb) for (size_t w = 0; w < B.size(); ++w) graph.bits[w] |= B[w];
+    if (sharded(h)) {
+      // union over the ranks through the sum exchange: E indicator digits per double in base (world + 1)
+      const int world = std::max(h->opt.world_size, 2);
+      int E = 1;
+      { double cap = 9007199254740992.0 / (world + 1); while (cap >= (world + 1) && E < 16) { cap /= (world + 1); ++E; } }
+      const int64_t nbits = (int64_t)ncv_real * ncv_real;
+      std::vector<double> packed((size_t)((nbits + E - 1) / E), 0.0);
+      for (int64_t q = 0; q < nbits; ++q)
+        if (graph.get((int)(q / ncv_real), (int)(q % ncv_real))) packed[(size_t)(q / E)] += std::pow((double)(world + 1), (double)(q % E));
+      if (int rc = allreduce_host(h, packed.data(), (int64_t)packed.size())) return rc;
+      for (size_t w = 0; w < packed.size(); ++w) {
+        double v = packed[w];
+        for (int e = 0; e < E && v > 0.0; ++e) {
+          const double d = std::fmod(v, (double)(world + 1));
+          v = std::floor(v / (world + 1));
+          const int64_t q = (int64_t)w * E + e;
+          if (d > 0.0 && q < nbits) graph.set((int)(q / ncv_real), (int)(q % ncv_real));
+        }
+      }
+    }
+    lap("camera graph");
+    int forced_depth = -2;
+    if (const char* e = std::getenv("MPSFM_CHOL_ND")) forced_depth = std::atoi(e);  // -1: caller's order, >= 0: dissection depth
+    int inv_rows = 2;
+    if (const char* e = std::getenv("MPSFM_CHOL_INVERSE")) if (std::atoi(e) == 0) inv_rows = -1;
+    plan_auto(graph, forced_depth, forced_depth >= -1, inv_rows < 0 ? 0 : dense_plain_max_tiles(), dense_inv_rows(), h->plan);
+    lap("camera order + factorisation plan");
+    h->nat_slot = h->plan.slot_of_nat;
+    h->ncv = h->plan.nslots;
+    h->n = 6 * h->ncv;
+    h->nt = (h->n + 31) / 32;
+    bool changed = false;
+    for (int i = 0; i < nc; ++i)
+      if (slot[(size_t)i] >= 0) { const int s2 = h->plan.slot_of_nat[(size_t)slot[(size_t)i]]; changed = changed || s2 != slot[(size_t)i]; slot[(size_t)i] = s2; }
+    if (changed) {
+      // records of a landmark stay sorted by (slot, camera); constant cameras last
+      parallel_ranges((int64_t)npu, 4096, [&](int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; ++p) {
+          for (int64_t r = prec[(size_t)p]; r < prec[(size_t)p + 1]; ++r) recs[(size_t)r].slot = slot[(size_t)recs[(size_t)r].cam];
+          std::stable_sort(recs.begin() + prec[(size_t)p], recs.begin() + prec[(size_t)p + 1], [](const Rec& a, const Rec& b) {
+            const int ka = a.slot < 0 ? INT32_MAX : a.slot, kb = b.slot < 0 ? INT32_MAX : b.slot;
+            if (ka != kb) return ka < kb;
+            return a.cam < b.cam;
+          });
+        }
+      });
+      for (Rec& r : fixed) r.slot = slot[(size_t)r.cam];
+      lap("records in the new camera order");
+    }
+  } else {
+    h->nat_slot.resize((size_t)ncv_real);
+    for (int i = 0; i < ncv_real; ++i) h->nat_slot[(size_t)i] = i;
+  }
   // -- landmark order: those with records sorted by their camera-slot list, then the rest that
   //    are referenced by fixed blocks only
   std::vector<int32_t> order; order.reserve(npu);
@@ -971,9 +1059,43 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     std::fprintf(stderr, "[mpsfm_ba] build: %zu chunks; per chunk: %.1f records, %.1f landmarks, %.1f cameras (max %d), %.1f work items (max %d), %.1f pairs\n",
                  chunks.size(), sr / n, sp / n, sc / n, mc, sb / n, mb, se / n);
   }
-  // -- block skyline of the reduced camera system (DenseEnvelope): which 6x6 blocks of S can be nonzero follows from the
-  //    static Schur pair tables; first_blk[c] = lowest camera slot that shares a landmark with slot c
-  {
+  // -- which 6x6 blocks of S exist, and the tables of the dense factorisation
+  if (use_graph) {
+    const int ns = h->ncv;
+    h->sky_index.assign((size_t)ns * (size_t)ns, -1);
+    int32_t nblk = 0;
+    for (int sj = 0; sj < ns; ++sj) {
+      const int j = h->plan.nat_of_slot[(size_t)sj];
+      if (j < 0) continue;
+      for (int si = 0; si <= sj; ++si) {
+        const int i = h->plan.nat_of_slot[(size_t)si];
+        if (i < 0) continue;
+        if (i == j || graph.get(i, j)) h->sky_index[(size_t)sj * ns + si] = nblk++;
+      }
+    }
+    h->sblk_blocks = nblk;
+    if (int rc2 = dev_upload(&h->d_sky_index, h->sky_index)) return rc2;
+    const CholPlan& PL = h->plan;
+    int rc2 = 0;
+    if ((rc2 = dev_upload(&h->d_lp_items, PL.items))) return rc2;
+    if ((rc2 = dev_upload(&h->d_lp_srcs, PL.srcs))) return rc2;
+    if ((rc2 = dev_upload(&h->d_lp_rows, PL.rows))) return rc2;
+    if ((rc2 = dev_upload(&h->d_lp_struct_start, PL.struct_start))) return rc2;
+    if ((rc2 = dev_upload(&h->d_lp_struct_rows, PL.struct_rows))) return rc2;
+    if ((rc2 = dev_upload(&h->d_lp_back_cols, PL.back_cols))) return rc2;
+    if ((rc2 = dev_upload(&h->d_lp_asm, PL.asm_tiles))) return rc2;
+    LevelPlanDev& D = h->lp;
+    D.valid = PL.nt >= 1; D.use_pinv = PL.use_pinv;
+    D.d_items = h->d_lp_items; D.d_srcs = h->d_lp_srcs; D.d_rows = h->d_lp_rows;
+    D.d_struct_start = h->d_lp_struct_start; D.d_struct_rows = h->d_lp_struct_rows; D.d_back_cols = h->d_lp_back_cols;
+    D.d_asm_tiles = h->d_lp_asm; D.n_asm = (int32_t)PL.asm_tiles.size(); D.nlevels = PL.nlevels;
+    D.h_launch_start = PL.launch_start.data(); D.h_back_start = PL.back_start.data();
+    if (h->opt.verbose >= 2)
+      std::fprintf(stderr, "[mpsfm_ba] build: camera order: %s (depth %d), %d slots for %d cameras, %d tile columns in %d levels, %lld tile products, %lld inverse roles, %d blocks of S\n",
+                   PL.nd_depth < 0 ? "caller's" : "nested dissection", PL.nd_depth, PL.nslots, PL.ncv, PL.nt, PL.nlevels, (long long)PL.products, (long long)PL.roles, nblk);
+  } else {
+    // block skyline (DenseEnvelope): which 6x6 blocks of S can be nonzero follows from the static Schur pair tables;
+    // first_blk[c] = lowest camera slot that shares a landmark with slot c
     const int ncv = h->ncv, nt = h->nt, n = h->n;
     std::vector<int32_t> first_blk((size_t)std::max(ncv, 1));
     for (int c = 0; c < ncv; ++c) first_blk[(size_t)c] = c;
@@ -1013,6 +1135,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     h->sky_first = first_blk;
     h->sky_start.assign((size_t)ncv + 1, 0);
     for (int c = 0; c < ncv; ++c) h->sky_start[(size_t)c + 1] = h->sky_start[(size_t)c] + (c - first_blk[(size_t)c] + 1);
+    h->sblk_blocks = h->sky_start[(size_t)ncv];
     if (int rc2 = dev_upload(&h->d_sky_first, h->sky_first)) return rc2;
     if (int rc2 = dev_upload(&h->d_sky_start, h->sky_start)) return rc2;
     std::vector<int32_t> first((size_t)nt + 1, 0);
@@ -1043,32 +1166,6 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     h->env.valid = nt >= 1;
     h->env.d_first = h->d_env_first; h->env.d_rows = h->d_env_rows; h->env.d_prow = h->d_env_prow;
     h->env.h_rows_start = h->env_rows_start.data(); h->env.h_prow_start = h->env_prow_start.data(); h->env.h_rows = h->env_rows.data();
-    // fused factorisation: one work item per tile of the skyline (rows k..nt of column k), taken by the workgroups in
-    // this order.  An item only waits for items in front of it: the tile (k+1,k) that also publishes the updated
-    // diagonal tile D(k+1) comes first in its column, the diagonal item (it only inverts L(k,k)) last.
-    {
-      const char* fe = std::getenv("MPSFM_CHOL_FUSED");
-      // off unless MPSFM_CHOL_FUSED=1: measured SLOWER than the per-step launches (C3: 0.69 vs 0.38 ms per solve — a tile
-      // handed between workgroups costs 2.8 us flag-to-flag plus 4-7 us until the consumer holds it, against 3.3 + 1.5 us
-      // for a launch boundary and a cold load); kept for A/B
-      if (fe && std::atoi(fe) == 1 && nt >= 1) {
-        std::vector<int32_t> items;
-        for (int k = 0; k < nt; ++k) {
-          for (int ti = k + 1; ti <= nt; ++ti) if (first[(size_t)ti] <= k) { items.push_back(ti); items.push_back(k); }
-          items.push_back(k); items.push_back(k);
-        }
-        const size_t nflags = ((size_t)(nt + 1) * (size_t)(nt + 2) / 2 + (size_t)nt + 1) * kFusedFlagStride;
-        if ((rc2 = dev_upload(&h->d_env_items, items))) return rc2;
-        if ((rc2 = dev_alloc(&h->d_env_flags, nflags))) return rc2;
-        if ((rc2 = dev_alloc(&h->d_env_ticket, 1))) return rc2;
-        HIP_TRY(hipMemset(h->d_env_flags, 0, sizeof(int32_t) * nflags));
-        HIP_TRY(hipMemset(h->d_env_ticket, 0, sizeof(uint32_t)));
-        h->env_ticket_base = 0; h->env_epoch = 0;
-        h->env.d_items = h->d_env_items; h->env.n_items = (int32_t)(items.size() / 2);
-        h->env.d_flags = h->d_env_flags; h->env.d_ticket = h->d_env_ticket;
-        h->env.h_ticket_base = &h->env_ticket_base; h->env.h_epoch = &h->env_epoch;
-      }
-    }
     if (h->opt.verbose >= 2) {
       int64_t inside = 0;
       for (int ti = 0; ti < nt; ++ti) inside += ti - first[(size_t)ti] + 1;
@@ -1124,7 +1221,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_cs, ncs * 6))) return rc;
   if ((rc = dev_alloc(&h->d_camtab, ncs * kCamRec))) return rc;
   if ((rc = dev_alloc(&h->d_camtab2, ncs * kCamRec))) return rc;
-  h->sblk_count = h->sky_start[(size_t)h->ncv] * 36;
+  h->sblk_count = h->sblk_blocks * 36;
   h->red_count = h->sblk_count + 3 * (int64_t)h->n + SC_COUNT;
   if ((rc = dev_alloc(&h->d_red, (size_t)h->red_count))) return rc;
   h->d_Sblk = h->d_red; h->d_gc = h->d_red + h->sblk_count; h->d_wv = h->d_gc + h->n; h->d_diagU = h->d_wv + h->n;
@@ -1147,6 +1244,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if (const char* e = std::getenv("MPSFM_CHOL_BIG")) h->ov.big = std::atoi(e) != 0;
   if (const char* e = std::getenv("MPSFM_CHOL_OVERLAP")) h->ov.overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("MPSFM_CHOL_INVERSE")) h->ov.no_inverse = std::atoi(e) == 0;
+  if (const char* e = std::getenv("MPSFM_CHOL_LEVEL")) h->ov.no_level = std::atoi(e) == 0;
   if (h->nt > 64 || h->ov.nb > 0) {
     HIP_TRY(pooled_stream(&h->ov.s2));
     for (auto& e : h->ov.evF) HIP_TRY(pooled_event(&e, false));
@@ -1206,7 +1304,7 @@ static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius) {
   a.camtab = h->d_camtab; a.pts = h->d_pts; a.ps = h->d_ps; a.loss = h->loss;
   a.radius = radius; a.min_diag = h->opt.min_lm_diagonal; a.max_diag = h->opt.max_lm_diagonal; a.ncv = h->ncv; a.dbg = (g_dbg_flags >> 8) & 0xff;
   a.lhdr = h->d_lhdr; a.nlong = h->nlong; a.nchunks = h->nchunks; a.cam_slot = h->d_cam_slot; a.wl = h->d_wl;
-  a.sky = BlockSky{h->d_sky_first, h->d_sky_start};
+  a.sky = BlockSky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv};
   a.Sblk = h->d_Sblk; a.gc = h->d_gc; a.wv = h->d_wv; a.diagU = h->d_diagU; a.part = h->d_part; a.diagV = h->d_diagV;
   a.yc = h->d_yc; a.camtab2 = h->d_camtab2; a.pts2 = h->d_pts2; a.part2 = h->d_part2;
   return a;
@@ -1265,10 +1363,14 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
   hipStream_t s = h->stream;
   // d_fail is zero here: cleared at creation and re-armed by k_cam_update after every read
   if (h->n > 0) {
-    AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius, h->opt.min_lm_diagonal,
-                    h->opt.max_lm_diagonal, h->d_A, dense_pinv(h->d_dwork, h->nt, &h->ov, &h->env)};
+    // the level-scheduled factorisation without inverse accumulators only touches the tiles of its plan
+    const bool level = dense_level(&h->ov, &h->lp);
+    double* pinv = dense_pinv(h->d_dwork, h->nt, &h->ov, &h->env, &h->lp);
+    const bool listed = level && !pinv;
+    AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius,
+                    h->opt.min_lm_diagonal, h->opt.max_lm_diagonal, h->d_A, pinv, listed ? h->lp.d_asm_tiles : nullptr, listed ? h->lp.n_asm : 0};
     launch_assemble(as, s);
-    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->env);
+    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->env, &h->lp);
   }
   return 0;
 }
@@ -1282,7 +1384,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   HIP_TRY(hipStreamSynchronize(s));
   const auto t_begin = clk::now();
   sum->num_residual_blocks = (int64_t)h->nblocks_global;
-  sum->reduced_dim = h->n;
+  sum->reduced_dim = h->n_user;
   int64_t n_cost_evals = 0, n_jac_evals = 0;
 
   // camera table at the initial point (unit scales) for the fixed cost
@@ -1373,8 +1475,6 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     ++n_jac_evals; ++n_cost_evals;
     const double* sc = h->h_scal;
     const int h_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;  // set by the factorisation, published by k_cam_update
-    if (sc[U_CHOL_FAIL] == 2.0)  // a workgroup of k_chol_fused gave up waiting for a tile (its polls are bounded): never a valid step
-      return finish(fail(MPSFM_EHIP, "fused Cholesky: a hand-off between workgroups did not arrive within the poll bound (unset MPSFM_CHOL_FUSED to use the per-step path)"));
 
     // ---- decisions (Ceres trust_region_minimizer.cc order) ------------------------------------
     x_cost = sc[U_X_COST];
@@ -1636,7 +1736,7 @@ int mpsfm_ba_eval_cost(mpsfm_ba_handle* h, double* cost_reproj, double* cost_dep
   return 0;
 }
 
-int mpsfm_ba_reduced_dim(mpsfm_ba_handle* h) { return h ? h->n : MPSFM_EINVAL; }
+int mpsfm_ba_reduced_dim(mpsfm_ba_handle* h) { return h ? h->n_user : MPSFM_EINVAL; }
 
 int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms) {
   if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
@@ -1673,36 +1773,39 @@ int mpsfm_ba_dense_solve_once(mpsfm_ba_handle* h, float* elapsed_ms) {
 }
 
 // S and rhs of the last sweep (with the LM damping of its radius), plus the last dense solution
+// S and the right-hand side in the CALLER's camera order (6 rows per variable camera), whatever slot order the handle uses.
 int mpsfm_ba_get_reduced_system(mpsfm_ba_handle* h, double* S, double* rhs, int32_t n) {
   if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
-  if (n != h->n) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
+  if (n != h->n_user) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
   HIP_TRY(hipSetDevice(h->device));
   std::vector<double> red((size_t)h->red_count);
   HIP_TRY(hipMemcpy(red.data(), h->d_red, sizeof(double) * red.size(), hipMemcpyDeviceToHost));
-  const double* Sb = red.data(); const double* gc = Sb + h->sblk_count; const double* wv = gc + n; const double* dU = wv + n;
+  const double* Sb = red.data(); const double* gc = Sb + h->sblk_count; const double* wv = gc + h->n; const double* dU = wv + h->n;
   const mpsfm_ba_options& o = h->opt;
+  const BlockSky sky{h->sky_first.data(), h->sky_start.data(), h->sky_index.empty() ? nullptr : h->sky_index.data(), h->ncv};
   for (int R = 0; R < n; ++R)
     for (int C = 0; C < n; ++C) {
-      const int br = R / 6, a = R % 6, bc = C / 6, b = C % 6;
+      const int br = h->nat_slot[(size_t)(R / 6)], a = R % 6, bc = h->nat_slot[(size_t)(C / 6)], b = C % 6;
       double v;
-      const BlockSky sky{h->sky_first.data(), h->sky_start.data()};
       const int lo = std::min(br, bc), hi = std::max(br, bc);
-      if (lo < sky.first[hi]) v = 0.0;
+      if (!sky_has(sky, lo, hi)) v = 0.0;
       else if (br < bc) v = Sb[sky_block(sky, br, bc) * 36 + a * 6 + b];
       else if (br > bc) v = Sb[sky_block(sky, bc, br) * 36 + b * 6 + a];
       else v = Sb[sky_block(sky, br, br) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
-      if (R == C) v += std::min(std::max(dU[R], o.min_lm_diagonal), o.max_lm_diagonal) / h->last_radius;
+      if (R == C) v += std::min(std::max(dU[6 * br + a], o.min_lm_diagonal), o.max_lm_diagonal) / h->last_radius;
       if (S) S[(size_t)R * n + C] = v;
     }
-  if (rhs) for (int i = 0; i < n; ++i) rhs[i] = wv[i] - gc[i];
+  if (rhs) for (int i = 0; i < n; ++i) { const int q = 6 * h->nat_slot[(size_t)(i / 6)] + i % 6; rhs[i] = wv[q] - gc[q]; }
   return 0;
 }
 
 int mpsfm_ba_get_dense_solution(mpsfm_ba_handle* h, double* y, int32_t n) {
   if (!h || !y) return fail(MPSFM_EINVAL, "handle or y is NULL");
-  if (n != h->n) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
+  if (n != h->n_user) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpy(y, h->d_yc, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  std::vector<double> ys((size_t)std::max(h->n, 1));
+  HIP_TRY(hipMemcpy(ys.data(), h->d_yc, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) y[i] = ys[(size_t)(6 * h->nat_slot[(size_t)(i / 6)] + i % 6)];
   return 0;
 }
 

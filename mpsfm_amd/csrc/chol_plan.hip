@@ -1,0 +1,397 @@
+// Ordering, symbolic factorisation and launch tables of the level-scheduled tile Cholesky (host code only; see chol_plan.h).
+#include "chol_plan.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <utility>
+
+#include "../../include/mpsfm_hip.h"
+
+namespace mpsfm {
+namespace {
+
+constexpr int kSegAlign = 16;    // slots per alignment unit: 16 cameras x 6 columns = 3 tiles
+constexpr int kMoveUpMax = 4;    // a segment with this many cameras beyond a multiple of 16 hands them to its parent instead of padding
+constexpr int kMinLeaf = 48;     // no dissection below this many cameras
+constexpr int kMinBfsLevels = 5;
+
+using Mask = std::vector<uint64_t>;
+
+struct Sub {  // breadth-first search inside a node subset
+  const CamGraph& g;
+  Mask in, seen;
+  explicit Sub(const CamGraph& g_) : g(g_), in((size_t)g_.words, 0), seen((size_t)g_.words, 0) {}
+  void set_nodes(const std::vector<int>& nodes) {
+    std::fill(in.begin(), in.end(), 0);
+    for (int v : nodes) in[(size_t)(v >> 6)] |= 1ull << (v & 63);
+  }
+  int degree(int v) const {
+    int d = 0;
+    const uint64_t* r = g.row(v);
+    for (int w = 0; w < g.words; ++w) d += __builtin_popcountll(r[w] & in[(size_t)w]);
+    return d;
+  }
+  // order: nodes by level, level_start: offsets (last entry = size).  Only nodes of `in` that are not in `seen` yet.
+  void bfs(int start, std::vector<int>& order, std::vector<int>& level_start, bool reset_seen) {
+    if (reset_seen) std::fill(seen.begin(), seen.end(), 0);
+    order.clear(); level_start.clear();
+    order.push_back(start); seen[(size_t)(start >> 6)] |= 1ull << (start & 63);
+    level_start.push_back(0);
+    size_t lo = 0;
+    while (lo < order.size()) {
+      const size_t hi = order.size();
+      for (size_t q = lo; q < hi; ++q) {
+        const uint64_t* r = g.row(order[q]);
+        for (int w = 0; w < g.words; ++w) {
+          uint64_t m = r[w] & in[(size_t)w] & ~seen[(size_t)w];
+          seen[(size_t)w] |= m;
+          while (m) { order.push_back(w * 64 + __builtin_ctzll(m)); m &= m - 1; }
+        }
+      }
+      lo = hi;
+      if (order.size() > hi) level_start.push_back((int)hi);
+    }
+    level_start.push_back((int)order.size());
+  }
+};
+
+void components(Sub& S, const std::vector<int>& nodes, std::vector<std::vector<int>>& comps) {
+  comps.clear();
+  S.set_nodes(nodes);
+  std::fill(S.seen.begin(), S.seen.end(), 0);
+  std::vector<int> order, ls;
+  for (int v : nodes) {
+    if ((S.seen[(size_t)(v >> 6)] >> (v & 63)) & 1) continue;
+    S.bfs(v, order, ls, false);
+    comps.push_back(order);
+    std::sort(comps.back().begin(), comps.back().end());
+  }
+}
+
+// a node far from the "middle" of a connected subset: repeated BFS from a lowest-degree node of the last level
+int pseudo_peripheral(Sub& S, const std::vector<int>& nodes, std::vector<int>& order, std::vector<int>& ls) {
+  S.set_nodes(nodes);
+  int s = nodes[0], best = 1 << 30;
+  for (int v : nodes) { const int d = S.degree(v); if (d < best) { best = d; s = v; } }
+  int depth = -1;
+  for (int it = 0; it < 8; ++it) {
+    S.bfs(s, order, ls, true);
+    const int nl = (int)ls.size() - 1;
+    if (nl <= depth) break;
+    depth = nl;
+    int cand = s, bd = 1 << 30;
+    for (int q = ls[(size_t)nl - 1]; q < ls[(size_t)nl]; ++q) { const int d = S.degree(order[(size_t)q]); if (d < bd) { bd = d; cand = order[(size_t)q]; } }
+    if (cand == s) break;
+    s = cand;
+  }
+  S.bfs(s, order, ls, true);
+  return s;
+}
+
+// reverse Cuthill-McKee of a subset (every component from a pseudo-peripheral node)
+void rcm(Sub& S, const std::vector<int>& nodes, std::vector<int>& out) {
+  std::vector<std::vector<int>> comps;
+  components(S, nodes, comps);
+  std::vector<int> order, ls;
+  for (const auto& c : comps) {
+    pseudo_peripheral(S, c, order, ls);
+    out.insert(out.end(), order.rbegin(), order.rend());
+  }
+}
+
+struct Seg { std::vector<int> cams; std::vector<int> child; };
+
+int dissect(Sub& S, std::vector<Seg>& tree, const std::vector<int>& nodes, int depth) {
+  const int me = (int)tree.size();
+  tree.emplace_back();
+  std::vector<std::vector<int>> comps;
+  components(S, nodes, comps);
+  if (comps.size() > 1) {  // independent parts: an empty separator above them
+    for (const auto& c : comps) { const int ch = dissect(S, tree, c, depth); tree[(size_t)me].child.push_back(ch); }
+    return me;
+  }
+  std::vector<int> order, ls;
+  if (depth > 0 && (int)nodes.size() >= kMinLeaf) {
+    pseudo_peripheral(S, nodes, order, ls);
+    const int nl = (int)ls.size() - 1;
+    if (nl >= kMinBfsLevels) {
+      // the level whose removal leaves the smallest larger side plus itself
+      int bm = -1; long best = 1L << 60;
+      for (int m = 1; m < nl - 1; ++m) {
+        const long a = ls[(size_t)m], b = (long)order.size() - ls[(size_t)m + 1], s = ls[(size_t)m + 1] - ls[(size_t)m];
+        const long cost = std::max(a, b) + s;
+        if (cost < best) { best = cost; bm = m; }
+      }
+      if (bm > 0) {
+        std::vector<int> A(order.begin(), order.begin() + ls[(size_t)bm]), B(order.begin() + ls[(size_t)bm + 1], order.end()),
+            sep(order.begin() + ls[(size_t)bm], order.begin() + ls[(size_t)bm + 1]);
+        std::sort(A.begin(), A.end()); std::sort(B.begin(), B.end()); std::sort(sep.begin(), sep.end());
+        const int ca = dissect(S, tree, A, depth - 1);
+        const int cb = dissect(S, tree, B, depth - 1);
+        tree[(size_t)me].child = {ca, cb};
+        rcm(S, sep, tree[(size_t)me].cams);
+        return me;
+      }
+    }
+  }
+  rcm(S, nodes, tree[(size_t)me].cams);
+  return me;
+}
+
+// Post-order flattening.  Every segment but the last one is made a multiple of kSegAlign slots: a few surplus cameras move
+// up into the parent's separator (still a separator), otherwise dummy slots (-1) pad it.
+void flatten(const std::vector<Seg>& tree, int node, bool is_root, std::vector<int>& out, std::vector<int>& up) {
+  std::vector<int> cams;
+  for (int c : tree[(size_t)node].child) {
+    std::vector<int> moved;
+    flatten(tree, c, false, out, moved);
+    cams.insert(cams.end(), moved.begin(), moved.end());
+  }
+  const std::vector<int>& own = tree[(size_t)node].cams;
+  if (!is_root && own.empty()) { up = cams; return; }  // nothing of its own: whatever moved up keeps moving
+  cams.insert(cams.end(), own.begin(), own.end());
+  if (!is_root) {
+    const int r = (int)cams.size() % kSegAlign;
+    if (r > 0 && r <= kMoveUpMax && (int)cams.size() > kSegAlign) {
+      up.assign(cams.end() - r, cams.end());
+      cams.resize(cams.size() - (size_t)r);
+    } else if (r > 0) {
+      cams.insert(cams.end(), (size_t)(kSegAlign - r), -1);
+    }
+  }
+  out.insert(out.end(), cams.begin(), cams.end());
+}
+
+}  // namespace
+
+void order_cameras(const CamGraph& g, int depth, std::vector<int32_t>& slot_of_nat, int& nslots) {
+  slot_of_nat.assign((size_t)g.n, -1);
+  if (depth < 0 || g.n == 0) {
+    for (int i = 0; i < g.n; ++i) slot_of_nat[(size_t)i] = i;
+    nslots = g.n;
+    return;
+  }
+  Sub S(g);
+  std::vector<Seg> tree;
+  std::vector<int> all((size_t)g.n);
+  for (int i = 0; i < g.n; ++i) all[(size_t)i] = i;
+  dissect(S, tree, all, depth);
+  std::vector<int> out, up;
+  flatten(tree, 0, true, out, up);
+  nslots = (int)out.size();
+  for (int s = 0; s < nslots; ++s) if (out[(size_t)s] >= 0) slot_of_nat[(size_t)out[(size_t)s]] = s;
+}
+
+void tile_pattern(const CamGraph& g, const std::vector<int32_t>& slot_of_nat, int nslots, std::vector<uint8_t>& pat, int& nt) {
+  const int n = 6 * nslots;
+  nt = (n + 31) / 32;
+  pat.assign((size_t)nt * (size_t)nt, 0);
+  auto mark = [&](int sa, int sb) {
+    const int a0 = (6 * sa) / 32, a1 = (6 * sa + 5) / 32, b0 = (6 * sb) / 32, b1 = (6 * sb + 5) / 32;
+    for (int a = a0; a <= a1; ++a)
+      for (int b = b0; b <= b1; ++b) { if (a > b) pat[(size_t)a * nt + b] = 1; else if (b > a) pat[(size_t)b * nt + a] = 1; }
+  };
+  for (int i = 0; i < g.n; ++i) {
+    const int si = slot_of_nat[(size_t)i];
+    mark(si, si);
+    const uint64_t* r = g.row(i);
+    for (int w = 0; w < g.words; ++w) {
+      uint64_t m = r[w];
+      while (m) {
+        const int j = w * 64 + __builtin_ctzll(m);
+        m &= m - 1;
+        if (j > i && j < g.n) mark(si, slot_of_nat[(size_t)j]);
+      }
+    }
+  }
+}
+
+void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, int inv_rows, CholPlan& P) {
+  P.nt = nt; P.use_pinv = use_pinv;
+  P.struct_start.assign((size_t)nt + 1, 0); P.struct_rows.clear();
+  P.parent.assign((size_t)nt, -1); P.level.assign((size_t)nt, 0);
+  P.items.clear(); P.launch_start.clear(); P.srcs.clear(); P.rows.clear(); P.asm_tiles.clear();
+  P.back_cols.clear(); P.back_start.clear();
+  P.products = 0; P.roles = 0; P.nlevels = 0;
+  if (nt <= 0) { P.launch_start.push_back(0); P.back_start.push_back(0); return; }
+  const int W = (nt + 1 + 63) / 64;
+  // symbolic factorisation: struct(j) = pattern of column j below the diagonal, plus struct(c) \ {j} of the children c
+  std::vector<uint64_t> st((size_t)nt * (size_t)W, 0);
+  std::vector<std::vector<int>> children((size_t)nt);
+  auto bit = [&](int j, int i) -> bool { return (st[(size_t)j * W + (i >> 6)] >> (i & 63)) & 1; };
+  for (int j = 0; j < nt; ++j) {
+    uint64_t* s = st.data() + (size_t)j * W;
+    for (int i = j + 1; i < nt; ++i) if (pat[(size_t)i * nt + j]) s[i >> 6] |= 1ull << (i & 63);
+    s[nt >> 6] |= 1ull << (nt & 63);  // the right-hand-side row
+    for (int c : children[(size_t)j]) {
+      const uint64_t* sc = st.data() + (size_t)c * W;
+      for (int w = 0; w < W; ++w) s[w] |= sc[w];
+    }
+    for (int i = 0; i <= j; ++i) s[i >> 6] &= ~(1ull << (i & 63));
+    int par = -1;
+    for (int i = j + 1; i < nt; ++i) if (bit(j, i)) { par = i; break; }
+    P.parent[(size_t)j] = par;
+    if (par >= 0) children[(size_t)par].push_back(j);
+    int lv = 0;
+    for (int c : children[(size_t)j]) lv = std::max(lv, P.level[(size_t)c] + 1);
+    P.level[(size_t)j] = lv;
+    P.nlevels = std::max(P.nlevels, lv + 1);
+  }
+  for (int j = 0; j < nt; ++j) {
+    for (int i = j + 1; i <= nt; ++i) if (bit(j, i)) P.struct_rows.push_back(i);
+    P.struct_start[(size_t)j + 1] = (int32_t)P.struct_rows.size();
+  }
+  auto rows_of = [&](int j) { return std::make_pair(P.struct_rows.data() + P.struct_start[(size_t)j], P.struct_rows.data() + P.struct_start[(size_t)j + 1]); };
+  auto lt = [](int64_t ti, int64_t tj) { return (int32_t)(ti * (ti + 1) / 2 + tj); };
+  for (int j = 0; j < nt; ++j) {
+    P.asm_tiles.push_back(lt(j, j));
+    auto r = rows_of(j);
+    for (const int32_t* p = r.first; p != r.second; ++p) P.asm_tiles.push_back(lt(*p, j));
+  }
+  std::sort(P.asm_tiles.begin(), P.asm_tiles.end());
+  // subtree lists (inverse roles): the descendants of j, j included
+  std::vector<std::vector<int>> subtree;
+  if (use_pinv) {
+    subtree.resize((size_t)nt);
+    for (int j = 0; j < nt; ++j) {
+      for (int c : children[(size_t)j]) subtree[(size_t)j].insert(subtree[(size_t)j].end(), subtree[(size_t)c].begin(), subtree[(size_t)c].end());
+      subtree[(size_t)j].push_back(j);
+      std::sort(subtree[(size_t)j].begin(), subtree[(size_t)j].end());
+    }
+  }
+  std::vector<std::vector<int>> by_level((size_t)P.nlevels);
+  for (int j = 0; j < nt; ++j) by_level[(size_t)P.level[(size_t)j]].push_back(j);
+  // launch l: the panels of the columns of level l; trailing updates and inverse roles from the columns of level l-1
+  for (int l = 0; l < P.nlevels; ++l) {
+    P.launch_start.push_back((int32_t)P.items.size());
+    for (int c : by_level[(size_t)l]) {
+      // children whose level is l-1 reach column c through the panel items; deeper children went through trailing items
+      std::vector<int> kids;
+      for (int k : children[(size_t)c]) if (P.level[(size_t)k] == l - 1) kids.push_back(k);
+      auto r = rows_of(c);
+      for (int q = -1; q < (int)(r.second - r.first); ++q) {
+        const int ti = q < 0 ? c : r.first[q];
+        CholItem it{kItemPanel, (uint16_t)ti, (uint16_t)c, (uint16_t)kids.size(), (uint32_t)P.srcs.size(), 0};
+        for (int k : kids) P.srcs.push_back(k | ((ti != c && bit(k, ti)) ? kSrcX : 0));
+        P.items.push_back(it);
+      }
+    }
+    if (l == 0) continue;
+    if (use_pinv) {
+      for (int j : by_level[(size_t)l - 1]) {
+        auto r = rows_of(j);
+        const int nrr = (int)(r.second - r.first) - 1;  // without the right-hand-side row
+        for (int g0 = 0; g0 < nrr; g0 += inv_rows) {
+          const int nr = std::min(inv_rows, nrr - g0);
+          const uint32_t off = (uint32_t)P.rows.size();
+          for (int q = 0; q < nr; ++q) P.rows.push_back(r.first[g0 + q]);
+          for (int k : subtree[(size_t)j]) { P.items.push_back(CholItem{kItemRole, (uint16_t)j, (uint16_t)k, (uint16_t)nr, 0, off}); ++P.roles; }
+        }
+      }
+    }
+    std::map<std::pair<int, int>, std::vector<int>> trail;  // (tk, ti) -> source columns
+    for (int k : by_level[(size_t)l - 1]) {
+      auto r = rows_of(k);
+      const int par = P.parent[(size_t)k];
+      for (const int32_t* pk = r.first; pk != r.second; ++pk) {
+        const int tk = *pk;
+        if (tk >= nt) continue;
+        if (tk == par && P.level[(size_t)par] == l) continue;  // the panel items of column par take this source
+        for (const int32_t* pi = pk; pi != r.second; ++pi) trail[{tk, *pi}].push_back(k);
+      }
+    }
+    for (auto& e : trail) {
+      CholItem it{kItemTrail, (uint16_t)e.first.second, (uint16_t)e.first.first, (uint16_t)e.second.size(), (uint32_t)P.srcs.size(), 0};
+      for (int k : e.second) P.srcs.push_back(k);
+      P.items.push_back(it);
+      P.products += (int64_t)e.second.size();
+    }
+  }
+  P.launch_start.push_back((int32_t)P.items.size());
+  for (const CholItem& it : P.items) if (it.type == kItemPanel) P.products += it.nsrc;
+  for (int l = P.nlevels - 1; l >= 0; --l) {
+    P.back_start.push_back((int32_t)P.back_cols.size());
+    for (int j : by_level[(size_t)l]) P.back_cols.push_back(j);
+  }
+  P.back_start.push_back((int32_t)P.back_cols.size());
+  // launch-cost model (measured on MI355X: a dependent launch ~9.5 us whatever it holds up to a few hundred workgroups)
+  P.est_us = 9.5 * P.nlevels + 0.02 * (double)P.products + 0.004 * (double)P.roles + (use_pinv ? 10.0 : 6.5 * P.nlevels);
+}
+
+void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_tiles, int inv_rows, CholPlan& best) {
+  int dmax = -1;
+  for (int s = g.n; s >= 2 * kMinLeaf; s /= 2) ++dmax;  // leaves of at least kMinLeaf cameras
+  dmax = std::min(dmax + 1, 5);
+  bool have = false;
+  for (int d = -1; d <= (forced ? -1 : dmax); ++d) {
+    const int depth = forced ? forced_depth : d;
+    CholPlan P;
+    P.ncv = g.n; P.nd_depth = depth;
+    order_cameras(g, depth, P.slot_of_nat, P.nslots);
+    P.n = 6 * P.nslots;
+    std::vector<uint8_t> pat;
+    int nt = 0;
+    tile_pattern(g, P.slot_of_nat, P.nslots, pat, nt);
+    plan_from_pattern(pat, nt, nt <= pinv_max_tiles, inv_rows, P);
+    if (!have || P.est_us < best.est_us - 1e-9) { best = std::move(P); have = true; }
+  }
+  best.nat_of_slot.assign((size_t)best.nslots, -1);
+  for (int i = 0; i < g.n; ++i) best.nat_of_slot[(size_t)best.slot_of_nat[(size_t)i]] = i;
+}
+
+}  // namespace mpsfm
+
+// ---- test hook: the plan of a camera graph, without a device (tests/test_chol_plan_cpu.py interprets the item tables with
+// NumPy and compares with a dense Cholesky) ------------------------------------------------------------------------------
+extern "C" {
+
+struct mpsfm_plan_handle { mpsfm::CholPlan P; };
+
+// adj: n x n bytes (symmetric, nonzero = the cameras share a landmark).  depth -2: choose; >= -1: that order.
+mpsfm_plan_handle* mpsfm_debug_plan_create(const uint8_t* adj, int32_t n, int32_t depth, int32_t pinv_max_tiles, int32_t inv_rows) {
+  if (!adj || n < 0) return nullptr;
+  mpsfm::CamGraph g;
+  g.init(n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) if (i != j && adj[(size_t)i * n + j]) g.set(i, j);
+  auto* h = new mpsfm_plan_handle();
+  mpsfm::plan_auto(g, depth, depth >= -1, pinv_max_tiles, inv_rows, h->P);
+  return h;
+}
+void mpsfm_debug_plan_destroy(mpsfm_plan_handle* h) { delete h; }
+// what: 0 header {ncv, nslots, n, nt, nlevels, nd_depth, use_pinv, n_items, products, roles}; 1 slot_of_nat; 2 struct_start; 3 struct_rows;
+// 4 parent; 5 level; 6 items (4 int32 each: type | ti << 16, tk | nsrc << 16, src, aux); 7 launch_start; 8 srcs; 9 rows; 10 asm_tiles;
+// 11 back_cols; 12 back_start.  Returns the length; copies min(length, cap) entries.
+int64_t mpsfm_debug_plan_get(const mpsfm_plan_handle* h, int32_t what, int32_t* out, int64_t cap) {
+  if (!h) return -1;
+  const mpsfm::CholPlan& P = h->P;
+  std::vector<int32_t> tmp;
+  const std::vector<int32_t>* v = &tmp;
+  switch (what) {
+    case 0: tmp = {P.ncv, P.nslots, P.n, P.nt, P.nlevels, P.nd_depth, P.use_pinv ? 1 : 0, (int32_t)P.items.size(), (int32_t)P.products, (int32_t)P.roles}; break;
+    case 1: v = &P.slot_of_nat; break;
+    case 2: v = &P.struct_start; break;
+    case 3: v = &P.struct_rows; break;
+    case 4: v = &P.parent; break;
+    case 5: v = &P.level; break;
+    case 6:
+      for (const mpsfm::CholItem& it : P.items) {
+        tmp.push_back((int32_t)(it.type | ((uint32_t)it.ti << 16))); tmp.push_back((int32_t)(it.tk | ((uint32_t)it.nsrc << 16)));
+        tmp.push_back((int32_t)it.src); tmp.push_back((int32_t)it.aux);
+      }
+      break;
+    case 7: v = &P.launch_start; break;
+    case 8: v = &P.srcs; break;
+    case 9: v = &P.rows; break;
+    case 10: v = &P.asm_tiles; break;
+    case 11: v = &P.back_cols; break;
+    case 12: v = &P.back_start; break;
+    default: return -1;
+  }
+  if (out) std::memcpy(out, v->data(), sizeof(int32_t) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
+  return (int64_t)v->size();
+}
+
+}  // extern "C"

@@ -6,6 +6,7 @@
 #include <math.h>
 
 #include "../../include/mpsfm_hip.h"
+#include "chol_plan.h"
 
 namespace mpsfm {
 
@@ -190,11 +191,24 @@ __host__ __device__ inline int64_t ut_block(int64_t i, int64_t j, int64_t ncv) {
 // start[j] + (i - first[j]) — first[j] is the lowest camera slot that shares a landmark with slot j on ANY rank
 // (ba_solver.hip build()), so every block a sweep can touch exists, and the buffer the ranks all-reduce holds the blocks
 // that can be nonzero instead of all ncv (ncv + 1) / 2 (C4: 11 MB instead of 144 MB).
+//
+// Two forms.  index != NULL (up to kIndexMaxSlots slots): index[j * ns + i], i <= j, is the block's position or -1 — exactly
+// the blocks of camera pairs that share a landmark on some rank, whatever the slot order (the nested-dissection order of
+// chol_plan.h puts separator cameras last, whose skyline columns would be nearly full).  Otherwise the skyline proper:
+// column j keeps the blocks first[j] <= i <= j.
 struct BlockSky {
   const int32_t* first;
   const int64_t* start;
+  const int32_t* index;
+  int32_t ns;
 };
-__host__ __device__ inline int64_t sky_block(const BlockSky& k, int64_t i, int64_t j) { return k.start[j] + (i - k.first[j]); }
+constexpr int kIndexMaxSlots = 4096;
+__host__ __device__ inline bool sky_has(const BlockSky& k, int64_t i, int64_t j) {
+  return k.index ? k.index[j * k.ns + i] >= 0 : i >= k.first[j];
+}
+__host__ __device__ inline int64_t sky_block(const BlockSky& k, int64_t i, int64_t j) {
+  return k.index ? (int64_t)k.index[j * k.ns + i] : k.start[j] + (i - k.first[j]);
+}
 // packed index of lower-triangle tile (ti >= tj)
 __host__ __device__ inline int64_t lt_tile(int64_t ti, int64_t tj) { return ti * (ti + 1) / 2 + tj; }
 
@@ -262,6 +276,7 @@ struct DenseOverlap {
   int nb = 0;            // outer panel width in tile columns; 0: default (one panel up to 64 tile columns, else 8)
   bool big = true;       // LDS-staged 64x64 trailing update (false: per-tile workgroups, for A/B measurements)
   bool overlap = true;   // second-stream look-ahead
+  bool no_level = false;    // per-step skyline path instead of the level-scheduled factorisation (A/B measurements)
   bool no_inverse = false;  // plain path: back substitution by groups instead of the inverse propagation (A/B measurements)
   hipStream_t s2 = nullptr;
   hipEvent_t evF[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -272,7 +287,6 @@ struct DenseOverlap {
 // nonzero in S and in its Cholesky factor only for tj >= first[ti].  Per factorisation step j the rows that take part:
 //   rows(j)  = { ti > j : first[ti] <= j }  (L(ti, j) != 0; always ends with the right-hand-side row nt)
 //   prow(j)  = { ti >= j+1 : first[ti] <= j+1 }  (tiles of the panel column j+1 inside the skyline), j = -1 .. nt-2
-constexpr int kFusedFlagStride = 32;  // int32 per hand-off flag of k_chol_fused: one 128-byte line each
 struct DenseEnvelope {
   bool valid = false;
   const int32_t* d_first = nullptr;  // [nt+1]
@@ -281,13 +295,21 @@ struct DenseEnvelope {
   const int32_t* h_rows_start = nullptr;  // host: [nt]   offsets of rows(j)   (entry nt-1 = total)
   const int32_t* h_prow_start = nullptr;  // host: [nt+1] offsets of prow(j-1) (entry nt = total)
   const int32_t* h_rows = nullptr;        // host copy of the row lists (the launcher looks at rows(j)[0])
-  // fused factorisation (k_chol_fused: ONE launch, one workgroup per skyline tile, hand-offs by flags); d_items == NULL: off
-  const int32_t* d_items = nullptr;   // [n_items][2] = (ti, tk), in the order workgroups take them (a topological order)
-  int32_t n_items = 0;
-  int32_t* d_flags = nullptr;         // kFusedFlagStride x ([(nt+1)(nt+2)/2] epoch at which L(ti,tk) was stored | [nt+1] epoch of the updated D(k))
-  uint32_t* d_ticket = nullptr;       // running ticket counter (never reset: the host keeps the base of every launch)
-  uint32_t* h_ticket_base = nullptr;  // host: tickets handed out by earlier launches
-  int32_t* h_epoch = nullptr;         // host: epoch of the last launch
+};
+
+// Device tables of the level-scheduled factorisation (chol_plan.h), static per handle.
+struct LevelPlanDev {
+  bool valid = false, use_pinv = false;
+  const CholItem* d_items = nullptr;
+  const int32_t* d_srcs = nullptr;
+  const int32_t* d_rows = nullptr;
+  const int32_t* d_struct_start = nullptr;
+  const int32_t* d_struct_rows = nullptr;
+  const int32_t* d_back_cols = nullptr;
+  const int32_t* d_asm_tiles = nullptr;
+  int32_t n_asm = 0, nlevels = 0;
+  const int32_t* h_launch_start = nullptr;  // host: [nlevels + 1]
+  const int32_t* h_back_start = nullptr;    // host: [nlevels + 1]
 };
 
 struct AssembleArgs {
@@ -297,6 +319,8 @@ struct AssembleArgs {
   double radius, min_diag, max_diag;
   double* A;     // tiles
   double* Pinv;  // accumulators of the inverse propagation (same tile indexing as A), zeroed here; may be NULL
+  const int32_t* tile_list;  // packed ids of the tiles to assemble (one workgroup each), NULL: all (nt+1)(nt+2)/2
+  int32_t n_list;
 };
 
 

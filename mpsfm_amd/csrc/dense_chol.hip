@@ -19,7 +19,7 @@ constexpr int kPlainMaxTiles = 64;  // up to this many tile columns: one outer p
 // one workgroup per lower tile (including the rhs tile row)
 __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
   // decode tile id -> (ti, tj), ti >= tj, ti in [0, nt], tj in [0, nt-1]
-  const int64_t id = blockIdx.x;
+  const int64_t id = P.tile_list ? (int64_t)P.tile_list[blockIdx.x] : (int64_t)blockIdx.x;
   int ti = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
   while ((int64_t)ti * (ti + 1) / 2 > id) --ti;
   while ((int64_t)(ti + 1) * (ti + 2) / 2 <= id) ++ti;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
       } else {
         const int br = R / 6, a = R - br * 6, bc = C / 6, b = C - bc * 6;
         const int lo = br < bc ? br : bc, hi = br < bc ? bc : br;
-        if (lo < P.sky.first[hi]) v = 0.0;  // outside the block skyline: structurally zero
+        if (!sky_has(P.sky, lo, hi)) v = 0.0;  // no landmark shared by the two cameras: structurally zero
         else if (br < bc) v = P.Sblk[sky_block(P.sky, br, bc) * 36 + a * 6 + b];
         else if (br > bc) v = P.Sblk[sky_block(P.sky, bc, br) * 36 + b * 6 + a];
         else v = P.Sblk[sky_block(P.sky, br, br) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
@@ -534,297 +534,141 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_step(double* A, double* L
   MPSFM_STAMP(4);
 }
 
-// ---- fused factorisation: ONE launch, one workgroup per tile of the skyline, hand-offs by flags ---------------------
-// The per-step path pays a launch boundary (~3.3 us) and a cold reload of its operands (~1.5 us) per tile column, on
-// top of the 4.3 us stacked factorisation that is the real dependent chain.  A hand-off of a tile between two resident
-// workgroups (store, release, flag, poll, acquire, load) costs 1.0-1.6 us (scripts/micro/flag_latency.hip; a grid-wide
-// barrier is no cheaper than a launch: 3.3 us over 64 workgroups).  So the factorisation becomes a dataflow:
-//   item (ti, tk), ti > tk:  left-looking — X = A(ti,tk) - sum_{j < tk} L(ti,j) L(tk,j)^T as the operands arrive (flag per
-//                tile), then the stacked factorisation [D(tk); X] with the UPDATED diagonal tile D(tk) published by the
-//                item (tk, tk-1), store L(ti,tk), raise its flag;
-//   item (tk+1, tk) besides: D(tk+1) = A(tk+1,tk+1) - sum_{j <= tk} L(tk+1,j) L(tk+1,j)^T, the last term from its own
-//                registers, published to Dbuf — the only hand-off on the critical path of a tile column;
-//   item (tk, tk):           [D(tk); I] -> L(tk,tk)^-T for the back substitution (off the critical path).
-// Workgroups take items by a ticket (atomic counter), in an order in which every item only waits for items in front
-// of it, so the lowest unfinished item is always resident and never blocks: no deadlock whatever the number of
-// workgroups the chip holds at once and whatever else runs beside.  Flags hold the epoch of the launch that set them
-// (never cleared), the ticket counter keeps running (the host passes the base).  Every poll loop is bounded: on a miss
-// the workgroup raises fail = 2, stops waiting and still raises its own flags, so the grid drains; the host treats
-// fail == 2 as an error, never as a result.
-struct FusedArgs {
-  double* A; double* LinvT; double* Dbuf;
-  const int32_t* items; const int32_t* first;
-  int32_t* flagL; int32_t* flagD; uint32_t* ticket;
-  int* fail;
-  int32_t nt, n_items, epoch; uint32_t ticket_base; int32_t dbg;
+
+// ---- level-scheduled factorisation (chol_plan.h): one launch per level of the tile elimination tree --------------------
+// The same three kinds of workgroup as a right-looking step (k_chol_step with kStepEnv), driven by an item table:
+//   panel (ti, c)   the tile's column c is at this launch's level.  The updated diagonal tile D(c) and the own tile receive
+//                   the children of c that were factored in the previous launch (sources; the rest of the subtree came
+//                   through trailing items of earlier launches), then wave 0 factors the stacked [D(c); X];
+//   trail (ti, tk)  C -= sum over the source columns (all of the previous level that reach the tile: one workgroup per
+//                   tile, so independent chains never race on an ancestor's tile and the sum has a fixed order);
+//   role  (j, k)    inverse propagation for column j of the previous level and a column k of its subtree.
+struct LevelArgs {
+  double* A; double* LinvT; double* Pinv;
+  const CholItem* items; const int32_t* srcs; const int32_t* rows;
+  int* fail; int32_t nt, dbg;
 };
-constexpr int kFusedSpinMax = 1 << 21;  // polls of ~0.5-1 us each: seconds
-constexpr int kFlagStride = kFusedFlagStride;  // one 128-byte line per flag: polls of different flags go to different channels
-constexpr int kFusedChunk = 4;          // tile columns of the left-looking sum taken per wait
 
-__device__ __forceinline__ int flag_peek(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void flag_raise(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Tiles handed from one workgroup to another inside the launch are written and read with agent-scope relaxed atomics
-// (global_store / global_load ... sc1: written through to, and read from, the level all XCDs share).  The alternative —
-// plain accesses ordered by agent-scope release / acquire fences — writes back and invalidates the WHOLE L2 of the XCD
-// per hand-off (buffer_wbl2 / buffer_inv sc1): measured 3.5 us to publish a tile against 1.9 us this way.  Order: data
-// stores, s_waitcnt vmcnt(0) (acknowledged), then the flag; the reader polls the flag and only then issues its loads.
-__device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void quad_load_coh(const double* T, int lane, int mi, int ni, v4d& acc) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = ld_coh(T + (16 * mi + (lane >> 4) + 4 * r) * kTile + 16 * ni + (lane & 15));
-}
-__device__ __forceinline__ void quad_store_coh(double* T, int lane, int mi, int ni, const v4d& acc) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) st_coh(T + (16 * mi + (lane >> 4) + 4 * r) * kTile + 16 * ni + (lane & 15), acc[r]);
-}
-__device__ __forceinline__ void quad_operand_coh(const double* T, int lane, int b, double (&o)[8]) {
-  const double* p = T + (16 * b + (lane & 15)) * kTile + 8 * (lane >> 4);
-#pragma unroll
-  for (int s = 0; s < 8; ++s) o[s] = ld_coh(p + s);
-}
-
-// One lane: poll one flag until it holds `epoch` (bounded).  `nap`: s_sleep argument between polls.
-template <int NAP>
-__device__ __forceinline__ void flag_wait(const int32_t* p, int epoch, int* fail) {
-  for (int spins = 0; flag_peek(p) != epoch; ++spins) {
-    if ((spins & 63) == 63 && flag_peek(fail) == 2) break;
-    if (spins >= kFusedSpinMax) { atomicMax(fail, 2); break; }
-    __builtin_amdgcn_s_sleep(NAP);
-  }
-}
-// Wave 0, all lanes: wait until n1 flags from f1, n2 flags from f2 (consecutive tile columns) and (if not NULL) the flag
-// f3 hold `epoch`; one flag per lane and round, so the waits overlap.
-__device__ __forceinline__ void fused_wait(const int32_t* f1, int n1, const int32_t* f2, int n2, const int32_t* f3, int epoch, int* fail, int lane) {
-  const int n = n1 + n2 + (f3 ? 1 : 0);
-  for (int idx = lane; idx < n; idx += 64)
-    flag_wait<1>(idx < n1 ? f1 + idx * kFlagStride : (idx < n1 + n2 ? f2 + (idx - n1) * kFlagStride : f3), epoch, fail);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // keeps the tile loads behind the polls; no cache invalidate (ld_coh)
-}
-
-__global__ __launch_bounds__(kStepThreads) void k_chol_fused(FusedArgs F) {
+__global__ __launch_bounds__(kStepThreads) void k_chol_level(LevelArgs G) {
   __shared__ double s_T[kTile][kTile + 1];
   __shared__ double s_X[kTile][kTile + 1];
   __shared__ __attribute__((aligned(16))) double s_Lt[kTile * kTile];
-  __shared__ int s_q;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mi = wave & 1, ni = wave >> 1;
-  if (tid == 0) s_q = (int)(atomicAdd(F.ticket, 1u) - F.ticket_base);
-  __syncthreads();
-  const int q = s_q;
-  if (q < 0 || q >= F.n_items) return;
-  const int ti = F.items[2 * q], tk = F.items[2 * q + 1], nt = F.nt;
-  const bool diag = ti == tk, chain = (ti == tk + 1) && ti < nt;
-  const int fi = F.first[ti], fk = F.first[tk];
-  const int j0 = max(fi, fk);      // first tile column both rows have
-  const int lo = chain ? fi : j0;  // the chain item also accumulates D(ti) over every column of row ti
-  const bool needD = fk < tk;      // else nothing left of the diagonal in row tk: D(tk) = A(tk,tk)
-  double* C = F.A + lt_tile(ti, tk) * kTileElems;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mi = wave & 1, ni = wave >> 1;  // this wave's quadrant
+  if (G.dbg & 16) return;  // ablation: the launch chain alone
+  const CholItem it = G.items[blockIdx.x];
+  double* A = G.A;
+  if (it.type == kItemRole) {
+    if (G.dbg & 8) return;
+    inv_role(A, G.LinvT, G.Pinv, G.nt, it.ti, G.rows + it.aux, it.nsrc, it.tk, s_T, s_Lt);
+    return;
+  }
+  const int ti = it.ti, tk = it.tk, nsrc = it.nsrc;
+  const int32_t* src = G.srcs + it.src;
+  double* C = A + lt_tile(ti, tk) * kTileElems;
+  if (it.type == kItemTrail) {
+    v4d acc;
+    quad_load(C, kTile, lane, mi, ni, acc);
+    if (!(G.dbg & 4))
+      for (int q = 0; q < nsrc; ++q) {
+        const int c = src[q];
+        double a[8], b[8];
+        quad_operand(A + lt_tile(ti, c) * kTileElems, lane, mi, a);
+        quad_operand(A + lt_tile(tk, c) * kTileElems, lane, ni, b);
+        quad_gemm_sub(a, b, acc);
+      }
+    quad_store(C, kTile, lane, mi, ni, acc);
+    return;
+  }
+  // ---- panel tile of column tk ---------------------------------------------------------------
+  const int row = lane & 31;
+  const bool diag = (ti == tk);
   long long* tr = g_chol_trace ? g_chol_trace + ((size_t)tk * 2) * 8 : nullptr;
-  const bool trace_on = (chain || (diag && tk == nt - 1)) && tr != nullptr && wave == 0;
+  const bool trace_on = diag && tr != nullptr && wave == 0;
   MPSFM_STAMP(0);
-  // Far from its turn a workgroup polls slowly on ONE flag — the diagonal tile two columns back — so that only the
-  // items of the next few columns poll their operands at full rate (a hundred workgroups polling at once slow the
-  // flags and the tiles of the critical chain down: they share the memory-side path).
-  if (tk >= 3 && F.first[tk - 2] < tk - 2 && !(F.dbg & 32)) {
-    if (tid == 0) flag_wait<64>(F.flagD + (tk - 2) * kFlagStride, F.epoch, F.fail);
-    __syncthreads();
-  }
-  v4d xacc, dacc = {0, 0, 0, 0};
-  v4d dk;
-  if (!diag) {
-    quad_load(C, kTile, lane, mi, ni, xacc);
-    if (chain) quad_load(F.A + lt_tile(ti, ti) * kTileElems, kTile, lane, mi, ni, dacc);
-    const int32_t* fLi = F.flagL + lt_tile(ti, 0) * kFlagStride;
-    const int32_t* fLk = F.flagL + lt_tile(tk, 0) * kFlagStride;
-    // columns lo .. tk-1 in chunks: each chunk is taken as soon as its tiles are there (a row that reaches far to the left
-    // has nearly all of its sum behind it when the last column arrives); the last chunk also waits for D(tk)
-    const int jend = tk - 1;  // may be < lo: no column at all
-    int jb = lo;
-    do {
-      const int je = min(jb + kFusedChunk - 1, jend);
-      const bool final_chunk = je >= jend;
-      const int nI = je >= jb ? je - jb + 1 : 0;
-      const int kb = max(jb, j0);
-      const int nK = je >= kb ? je - kb + 1 : 0;
-      if (nI > 0 || (final_chunk && needD)) {
-        if (wave == 0)
-          fused_wait(fLi + jb * kFlagStride, nI, fLk + kb * kFlagStride, nK, (final_chunk && needD) ? F.flagD + tk * kFlagStride : nullptr, F.epoch, F.fail, lane);
-        __syncthreads();
-      }
-      if (final_chunk) {
-        MPSFM_STAMP(1);
-        if (needD) quad_load_coh(F.Dbuf + (size_t)tk * kTileElems, lane, mi, ni, dk);
-        else quad_load(F.A + lt_tile(tk, tk) * kTileElems, kTile, lane, mi, ni, dk);
-      }
-      if (!(F.dbg & 4)) {
-        // all operand loads of the chunk first, then the products
-        double am[kFusedChunk][8], bi[kFusedChunk][8], bk[kFusedChunk][8];
-#pragma unroll
-        for (int u = 0; u < kFusedChunk; ++u) {
-          const int j = jb + u;
-          if (j <= je) {
-            const double* Lij = F.A + lt_tile(ti, j) * kTileElems;
-            quad_operand_coh(Lij, lane, mi, am[u]);
-            if (chain) quad_operand_coh(Lij, lane, ni, bi[u]);
-            if (j >= j0) quad_operand_coh(F.A + lt_tile(tk, j) * kTileElems, lane, ni, bk[u]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kFusedChunk; ++u) {
-          const int j = jb + u;
-          if (j <= je) {
-            if (chain) quad_gemm_sub(am[u], bi[u], dacc);
-            if (j >= j0) quad_gemm_sub(am[u], bk[u], xacc);
-          }
+  {
+    v4d dacc, xacc;
+    quad_load(A + lt_tile(tk, tk) * kTileElems, kTile, lane, mi, ni, dacc);
+    if (!diag) quad_load(C, kTile, lane, mi, ni, xacc);
+    if (!(G.dbg & 4))
+      for (int q = 0; q < nsrc; ++q) {
+        const int e = src[q], c = e & 0xffff;
+        const double* Lk = A + lt_tile(tk, c) * kTileElems;
+        double am[8], bn[8];
+        quad_operand(Lk, lane, mi, am);
+        quad_operand(Lk, lane, ni, bn);
+        quad_gemm_sub(am, bn, dacc);
+        if (!diag && (e & kSrcX)) {
+          quad_operand(A + lt_tile(ti, c) * kTileElems, lane, mi, am);
+          quad_gemm_sub(am, bn, xacc);
         }
       }
-      jb = je + 1;
-    } while (jb <= jend);
-    quad_store(&s_T[0][0], kTile + 1, lane, mi, ni, dk);
-  } else {
-    if (needD) {
-      if (wave == 0) fused_wait(nullptr, 0, nullptr, 0, F.flagD + tk * kFlagStride, F.epoch, F.fail, lane);
-      __syncthreads();
+    quad_store(&s_T[0][0], kTile + 1, lane, mi, ni, dacc);
+    if (diag) {  // identity: x L^-T = row of L^-T
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xacc[r] = (16 * mi + (lane >> 4) + 4 * r == 16 * ni + (lane & 15)) ? 1.0 : 0.0;
     }
-    MPSFM_STAMP(1);
-    if (needD) quad_load_coh(F.Dbuf + (size_t)tk * kTileElems, lane, mi, ni, dk);
-    else quad_load(F.A + lt_tile(tk, tk) * kTileElems, kTile, lane, mi, ni, dk);
-    quad_store(&s_T[0][0], kTile + 1, lane, mi, ni, dk);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xacc[r] = (16 * mi + (lane >> 4) + 4 * r == 16 * ni + (lane & 15)) ? 1.0 : 0.0;  // x L^-T = row of L^-T
+    quad_store(&s_X[0][0], kTile + 1, lane, mi, ni, xacc);
   }
-  quad_store(&s_X[0][0], kTile + 1, lane, mi, ni, xacc);
+  MPSFM_STAMP(1);
   __syncthreads();
   MPSFM_STAMP(2);
-  if (wave != 0 && !chain) return;
-  const int row = lane & 31;
-  if (wave == 0) {
-    // stacked factorisation: lanes 0..31 rows of D, lanes 32..63 rows of X (identity for the diagonal item)
-    double a[kTile];
-    {
-      const double* src = (lane < kTile) ? &s_T[row][0] : &s_X[row][0];
-#pragma unroll
-      for (int c = 0; c < kTile; ++c) a[c] = src[c];
-    }
-    bool ok = true;
-    if (!(F.dbg & 1)) stacked_panel<0>(a, lane, s_Lt, ok);
-    MPSFM_STAMP(3);
-    if (diag && !ok && lane == 0) atomicMax(F.fail, 1);
-    if (lane >= kTile) {
-      if (chain) {
-#pragma unroll
-        for (int c = 0; c < kTile; ++c) s_X[row][c] = a[c];  // L(ti,tk) for the update of D(ti) (every wave is past its read of s_X)
-      }
-      if (diag) {  // read by the next launch only
-        double2* dst = reinterpret_cast<double2*>(F.LinvT + (size_t)tk * kTileElems + row * kTile);
-#pragma unroll
-        for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(a[c], a[c + 1]);
-      } else {
-#pragma unroll
-        for (int c = 0; c < kTile; ++c) st_coh(C + row * kTile + c, a[c]);
-      }
-    }
-    if (!chain) {
-      if (!diag) {
-        stores_done();
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) flag_raise(F.flagL + lt_tile(ti, tk) * kFlagStride, F.epoch);
-      }
-      return;
-    }
-  }
-  // chain item: D(ti) -= L(ti,tk) L(ti,tk)^T, publish it, then the flags of both tiles
-  __syncthreads();
+  if (wave != 0) return;
+  double a[kTile];
   {
-    double am[8], bn[8];
-    const int m16 = lane & 15, kg = lane >> 4;
+    const double* sp = (lane < kTile) ? &s_T[row][0] : &s_X[row][0];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { am[s] = s_X[16 * mi + m16][8 * kg + s]; bn[s] = s_X[16 * ni + m16][8 * kg + s]; }
-    quad_gemm_sub(am, bn, dacc);
-    quad_store_coh(F.Dbuf + (size_t)ti * kTileElems, lane, mi, ni, dacc);
+    for (int c = 0; c < kTile; ++c) a[c] = sp[c];
   }
-  stores_done();
-  __syncthreads();
-  if (tid == 0) {
-    flag_raise(F.flagD + ti * kFlagStride, F.epoch);
-    flag_raise(F.flagL + lt_tile(ti, tk) * kFlagStride, F.epoch);
+  bool ok = true;
+  if (!(G.dbg & 1)) stacked_panel<0>(a, lane, s_Lt, ok);
+  MPSFM_STAMP(3);
+  // as in k_chol_step the factored diagonal tile is not written back over A(tk,tk): its column's other workgroups may
+  // still be loading it
+  if (diag && !ok && lane == 0) atomicExch(G.fail, 1);
+  if (lane >= kTile) {
+    double2* dst = diag ? reinterpret_cast<double2*>(G.LinvT + (size_t)tk * kTileElems + row * kTile)
+                        : reinterpret_cast<double2*>(C + row * kTile);
+#pragma unroll
+    for (int c = 0; c < kTile; c += 2) dst[c >> 1] = make_double2(a[c], a[c + 1]);
   }
   MPSFM_STAMP(4);
 }
 
-// ---- back substitution y = L^-T z in ONE workgroup (after k_chol_fused) ----------------------------------------------
-// z (row 0 of the right-hand-side tiles) lives in LDS.  Step k: y_k = L(k,k)^-T z_k — every 32-lane part forms it
-// redundantly from its prefetched rows of the stored inverse, so no workgroup barrier separates it from the update —
-// then z_i -= L(k,i)^T y_k for the tiles of row k inside the skyline, one tile per part and round.  The operands of
-// step k-1 are requested before step k computes; one barrier per step.
-constexpr int kBs1Parts = 8;
-// workgroup barrier that waits for the LDS traffic only: __syncthreads() also waits for every global load in flight,
-// which here are the prefetches of the NEXT step
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void bs1_load(const double* A, const double* LinvT, const int32_t* first, int k, int c, int part, double (&v)[kTile], double (&t)[kTile]) {
-  const double2* Li = reinterpret_cast<const double2*>(LinvT + (size_t)k * kTileElems + c * kTile);
-#pragma unroll
-  for (int q = 0; q < kTile / 2; ++q) { const double2 x = Li[q]; v[2 * q] = x.x; v[2 * q + 1] = x.y; }
-  const int i = first[k] + part;
-  if (i < k) {
-    const double* T = A + lt_tile(k, i) * kTileElems + c;
-#pragma unroll
-    for (int r = 0; r < kTile; ++r) t[r] = T[r * kTile];
+// Backward substitution y = L^-T z by levels, highest first (no inverse accumulators: nt > kPlainMaxTiles).  One workgroup
+// per tile column j of the level: v = z_j - sum_{i in struct(j)} L(i,j)^T y_i (all those i are ancestors: final), then
+// y_j = L(j,j)^-T v with the stored inverse.  z_j is row 0 of the right-hand-side tile (nt, j).
+__global__ __launch_bounds__(256) void k_back_level(const double* A, const double* LinvT, const int32_t* cols, const int32_t* struct_start,
+                                                    const int32_t* struct_rows, int nt, int n, double* ybuf, double* y) {
+  __shared__ double s_part[8][kTile];
+  __shared__ double s_v[kTile];
+  const int j = cols[blockIdx.x];
+  const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int r0 = struct_start[j], r1 = struct_start[j + 1] - 1;  // the last entry is the right-hand-side row
+  double sacc = 0.0;
+  for (int q = r0 + part; q < r1; q += 8) {
+    const int i = struct_rows[q];
+    const double* Tl = A + lt_tile(i, j) * kTileElems + c;
+    const double* yi = ybuf + (size_t)i * kTile;
+#pragma unroll 8
+    for (int r = 0; r < kTile; ++r) sacc = __builtin_fma(Tl[r * kTile], yi[r], sacc);
   }
-}
-__device__ __forceinline__ void bs1_step(const double* A, const int32_t* first, int k, int n, int c, int part, const double (&v)[kTile], const double (&t)[kTile],
-                                         double* s_z, double* s_y, double* y) {
-  double yr = 0.0;
-  {
-    const double2* z = reinterpret_cast<const double2*>(s_z + k * kTile);
+  s_part[part][c] = sacc;
+  __syncthreads();
+  if (part == 0) {
+    double v = A[lt_tile(nt, j) * kTileElems + c];
 #pragma unroll
-    for (int q = 0; q < kTile / 2; ++q) { const double2 x = z[q]; yr = __builtin_fma(v[2 * q], x.x, yr); yr = __builtin_fma(v[2 * q + 1], x.y, yr); }
+    for (int q = 0; q < 8; ++q) v -= s_part[q][c];
+    s_v[c] = v;
   }
-  double* yp = s_y + part * kTile;
-  yp[c] = yr;
-  if (part == 0 && k * kTile + c < n) y[k * kTile + c] = yr;
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();  // a part is half a wave: its LDS operations complete in order
-  const int fk = first[k];
-  int i = fk + part;
-  if (i < k) {
-    double sacc = 0.0;
-    const double2* yy = reinterpret_cast<const double2*>(yp);
+  __syncthreads();
+  if (part == 0) {
+    const double* Li = LinvT + (size_t)j * kTileElems + c * kTile;
+    double yr = 0.0;
 #pragma unroll
-    for (int q = 0; q < kTile / 2; ++q) { const double2 x = yy[q]; sacc = __builtin_fma(t[2 * q], x.x, sacc); sacc = __builtin_fma(t[2 * q + 1], x.y, sacc); }
-    s_z[i * kTile + c] -= sacc;
-  }
-  for (i += kBs1Parts; i < k; i += kBs1Parts) {  // wide rows: on demand
-    const double* T = A + lt_tile(k, i) * kTileElems + c;
-    double w[kTile];
-#pragma unroll
-    for (int r = 0; r < kTile; ++r) w[r] = T[r * kTile];
-    double sacc = 0.0;
-#pragma unroll
-    for (int r = 0; r < kTile; ++r) sacc = __builtin_fma(w[r], yp[r], sacc);
-    s_z[i * kTile + c] -= sacc;
-  }
-}
-__global__ __launch_bounds__(kBs1Parts * kTile) void k_backsub_one(const double* A, const double* LinvT, const int32_t* first, int nt, int n, double* y) {
-  extern __shared__ __attribute__((aligned(16))) double s_bs1[];
-  double* s_z = s_bs1;
-  double* s_y = s_bs1 + (size_t)nt * kTile;
-  const int tid = threadIdx.x, c = tid & 31, part = tid >> 5;
-  for (int e = tid; e < nt * kTile; e += kBs1Parts * kTile) s_z[e] = A[lt_tile(nt, e >> 5) * kTileElems + (e & 31)];
-  double va[kTile], ta[kTile], vb[kTile], tb[kTile];
-  bs1_load(A, LinvT, first, nt - 1, c, part, va, ta);
-  for (int k = nt - 1; k >= 0; k -= 2) {
-    if (k >= 1) bs1_load(A, LinvT, first, k - 1, c, part, vb, tb);
-    lds_barrier();
-    bs1_step(A, first, k, n, c, part, va, ta, s_z, s_y, y);
-    if (k < 1) break;
-    if (k >= 2) bs1_load(A, LinvT, first, k - 2, c, part, va, ta);
-    lds_barrier();
-    bs1_step(A, first, k - 1, n, c, part, vb, tb, s_z, s_y, y);
+    for (int q = 0; q < kTile; ++q) yr = __builtin_fma(Li[q], s_v[q], yr);
+    ybuf[(size_t)j * kTile + c] = yr;
+    if (j * kTile + c < n) y[j * kTile + c] = yr;
   }
 }
 
@@ -968,7 +812,7 @@ __global__ __launch_bounds__(256) void k_inv_y(const double* Pinv, const double*
 
 // ---- host wrappers -----------------------------------------------------------------------------------
 void launch_assemble(const AssembleArgs& a, hipStream_t s) {
-  const int64_t ntiles = (int64_t)(a.nt + 1) * (a.nt + 2) / 2;
+  const int64_t ntiles = a.tile_list ? (int64_t)a.n_list : (int64_t)(a.nt + 1) * (a.nt + 2) / 2;
   hipLaunchKernelGGL(k_assemble, dim3((unsigned)ntiles), dim3(256), 0, s, a);
 }
 
@@ -980,50 +824,56 @@ static void launch_big(double* A, int nt, int j, int c0, int tk_lo, int tk_hi, h
   hipLaunchKernelGGL(k_big_update, dim3((rows + 1) / 2, (cols + 1) / 2), dim3(256), 0, s, A, nt, j, c0, tk_lo, tk_hi);
 }
 
-// layout of the work buffer: L^-T of the diagonal tiles | z | w | updated diagonal tiles (fused path) | inverse accumulators (per-step path, nt <= 64)
+// layout of the work buffer: L^-T of the diagonal tiles | z | w | one spare tile row | inverse accumulators (per-step path, nt <= 64)
 size_t dense_work_doubles(int nt) {
   const size_t t = (size_t)(nt > 0 ? nt : 1);
   size_t n = t * kTileElems + 2 * t * kTile + (t + 1) * kTileElems;
   if (nt <= kPlainMaxTiles) n += (t * (t + 1) / 2) * kTileElems;
   return n;
 }
-static bool dense_fused(int nt, const DenseOverlap* ov, const DenseEnvelope* env) {
-  return nt > 0 && env && env->valid && env->d_items && !(ov && ov->nb > 0);
-}
+int dense_plain_max_tiles() { return kPlainMaxTiles; }
+int dense_inv_rows() { return kInvRows; }
+bool dense_level(const DenseOverlap* ov, const LevelPlanDev* lp) { return lp && lp->valid && !(ov && (ov->nb > 0 || ov->no_level)); }
 static int dense_panel_width(int nt, const DenseOverlap* ov) {
   return (ov && ov->nb > 0) ? ov->nb : ((nt <= kPlainMaxTiles) ? nt : 8);
 }
 // the accumulators of the inverse propagation, or NULL when this solve does not use them (outer panels, switched off)
-double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const DenseEnvelope* env) {
-  if (nt <= 0 || nt > kPlainMaxTiles || (ov && (ov->no_inverse || ov->nb > 0)) || dense_fused(nt, ov, env)) return nullptr;
+double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const DenseEnvelope* env, const LevelPlanDev* lp) {
+  (void)env;
+  if (nt <= 0 || nt > kPlainMaxTiles || (ov && (ov->no_inverse || ov->nb > 0))) return nullptr;
+  if (dense_level(ov, lp) && !lp->use_pinv) return nullptr;
   return work + (size_t)nt * kTileElems + 2 * (size_t)nt * kTile + ((size_t)nt + 1) * kTileElems;
 }
 
 // ov (may be NULL): a second stream and events.  With it the update of an outer panel is split: the tile
 // columns of the NEXT panel are updated on the main stream (the factorisation needs them next), the columns
 // beyond run on the second stream under the next panel's factorisation steps.
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov, const DenseEnvelope* env) {
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov, const DenseEnvelope* env,
+                        const LevelPlanDev* lp) {
   if (nt <= 0) return;
   double* LinvT = work;
   double* zbuf = work + (size_t)nt * kTileElems;
   double* wbuf = zbuf + (size_t)nt * kTile;
   const StepEnv no_env{nullptr, nullptr, nullptr, 0, 0};
-  if (dense_fused(nt, ov, env)) {
-    const int32_t epoch = ++*env->h_epoch;
-    const uint32_t base = *env->h_ticket_base;
-    *env->h_ticket_base = base + (uint32_t)env->n_items;
-    FusedArgs F{A, LinvT, wbuf + (size_t)nt * kTile, env->d_items, env->d_first, env->d_flags, env->d_flags + (size_t)(nt + 1) * (size_t)(nt + 2) / 2 * kFusedFlagStride,
-                env->d_ticket, fail, nt, env->n_items, epoch, base, g_dbg_flags};
-    hipLaunchKernelGGL(k_chol_fused, dim3((unsigned)env->n_items), dim3(kStepThreads), 0, s, F);
-    const size_t lds = sizeof(double) * ((size_t)nt * kTile + kBs1Parts * kTile);
-    if (lds <= 64 * 1024) {
-      hipLaunchKernelGGL(k_backsub_one, dim3(1), dim3(kBs1Parts * kTile), lds, s, A, LinvT, env->d_first, nt, n, y);
-    } else {
-      hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
-      for (int t1 = nt; t1 > 0; t1 -= kBsG) {
-        const int t0 = t1 - kBsG > 0 ? t1 - kBsG : 0;
-        hipLaunchKernelGGL(k_backsub_group, dim3(t0 > 0 ? t0 : 1), dim3(256), 0, s, A, LinvT, nt, n, t0, t1, zbuf, y);
-      }
+  if (dense_level(ov, lp)) {
+    double* Pinv = dense_pinv(work, nt, ov, env, lp);
+    LevelArgs G{A, LinvT, Pinv, nullptr, lp->d_srcs, lp->d_rows, fail, nt, g_dbg_flags};
+    for (int l = 0; l < lp->nlevels; ++l) {
+      const int grid = lp->h_launch_start[l + 1] - lp->h_launch_start[l];
+      if (grid <= 0) continue;
+      G.items = lp->d_items + lp->h_launch_start[l];
+      hipLaunchKernelGGL(k_chol_level, dim3((unsigned)grid), dim3(kStepThreads), 0, s, G);
+    }
+    if (Pinv) {
+      hipLaunchKernelGGL(k_inv_w, dim3(nt), dim3(64), 0, s, A, LinvT, nt, n, wbuf, y);
+      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, Pinv, wbuf, nt, n, y);
+      return;
+    }
+    for (int l = 0; l < lp->nlevels; ++l) {
+      const int grid = lp->h_back_start[l + 1] - lp->h_back_start[l];
+      if (grid <= 0) continue;
+      hipLaunchKernelGGL(k_back_level, dim3((unsigned)grid), dim3(256), 0, s, A, LinvT, lp->d_back_cols + lp->h_back_start[l], lp->d_struct_start,
+                         lp->d_struct_rows, nt, n, zbuf, y);
     }
     return;
   }
@@ -1032,7 +882,7 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
     // nonzero (DenseEnvelope).  What Ceres gets from its sparse Cholesky (reference bundle_adjustment.py:288,
     // SPARSE_SCHUR): with cameras that only share landmarks with their neighbours most of S and of L is structurally
     // zero — at C3 232 of 741 tiles are inside the skyline and the trailing updates shrink 14-fold.
-    double* Pinv = dense_pinv(work, nt, ov, env);
+    double* Pinv = dense_pinv(work, nt, ov, env, lp);
     for (int j = -1; j <= nt - 2; ++j) {
       StepEnv E;
       E.first = env->d_first;
