@@ -199,13 +199,21 @@ int mpsfm_ba_eval_cost(mpsfm_ba_handle* h, double* cost_reproj, double* cost_dep
  * `elapsed_ms` receives the HIP-event time of that kernel alone. */
 int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms);
 /* Download the reduced camera system built by the last sweep: S (n x n, row-major, symmetric)
- * and rhs (n); n = summary.reduced_dim.  Test/diagnostic entry point. */
+ * and rhs (n); n = summary.reduced_dim = 6 x variable cameras, rows in the CALLER's camera order
+ * (the handle keeps its own slot order, see mpsfm_ba_dense_plan).  Test/diagnostic entry point. */
 int mpsfm_ba_get_reduced_system(mpsfm_ba_handle* h, double* S, double* rhs, int32_t n);
 int mpsfm_ba_reduced_dim(mpsfm_ba_handle* h);
 /* Solution y (scaled coordinates, length n) of the last dense solve.  Test/diagnostic. */
 int mpsfm_ba_get_dense_solution(mpsfm_ba_handle* h, double* y, int32_t n);
 /* Factor + solve only, on the last assembled system (prices the MFMA dense solve). */
 int mpsfm_ba_dense_solve_once(mpsfm_ba_handle* h, float* elapsed_ms);
+/* How the handle factors the reduced camera system (what Ceres' fill-reducing ordering and sparse
+ * Cholesky do behind bundle_adjustment.py:288).  info[0..9] = camera slots incl. alignment dummies,
+ * 32-column tile columns, levels of the tile elimination tree (= factorisation launches),
+ * nested-dissection depth (-1: caller's camera order), 1 if the back substitution uses the
+ * inverse accumulators, work items, tile products, inverse roles, 6x6 blocks of S stored,
+ * back-substitution launches. */
+int mpsfm_ba_dense_plan(mpsfm_ba_handle* h, int64_t info[10]);
 
 /* -- point covariances: replaces pycolmap.estimate_ba_covariance(POINTS)
  *    (bundle_adjustment.py:244-261).  cov[j] = (sum_i magnitude * Jp_i^T Jp_i)^-1 over the

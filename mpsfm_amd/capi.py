@@ -21,7 +21,7 @@ EXPORTS = [
     "mpsfm_ba_solve", "mpsfm_ba_create", "mpsfm_ba_set_state", "mpsfm_ba_reset_state",
     "mpsfm_ba_solve_resident", "mpsfm_ba_get_state", "mpsfm_ba_destroy", "mpsfm_ba_eval_cost",
     "mpsfm_ba_sweep_once", "mpsfm_ba_get_reduced_system", "mpsfm_ba_reduced_dim",
-    "mpsfm_ba_get_dense_solution", "mpsfm_ba_dense_solve_once", "mpsfm_point_covs",
+    "mpsfm_ba_get_dense_solution", "mpsfm_ba_dense_solve_once", "mpsfm_ba_dense_plan", "mpsfm_point_covs",
     "mpsfm_triangulate_tracks", "mpsfm_filter_tracks", "mpsfm_integrate_depth", "mpsfm_integrate_depth_batch",
     "mpsfm_integration_variances", "mpsfm_depth_blocks", "mpsfm_comm_unique_id",
 ]
@@ -61,6 +61,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         L.mpsfm_ba_reset_state.argtypes = [C.c_void_p]
         L.mpsfm_ba_reduced_dim.argtypes = [C.c_void_p]
+        L.mpsfm_ba_dense_plan.argtypes = [C.c_void_p, C.c_void_p]
         L.mpsfm_ba_destroy.argtypes = [C.c_void_p]
         L.mpsfm_ba_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mpsfm_ba_solve.argtypes = [C.c_void_p] * 4
@@ -165,6 +166,14 @@ class BAHandle:
     @property
     def reduced_dim(self) -> int:
         return int(lib().mpsfm_ba_reduced_dim(self._h))
+
+    def dense_plan(self) -> dict:
+        """How the handle factors the reduced camera system (slot order, elimination-tree levels, launch counts)."""
+        v = (C.c_int64 * 10)()
+        _check(lib().mpsfm_ba_dense_plan(self._h, v))
+        keys = ["slots", "tile_columns", "levels", "nd_depth", "inverse_accumulators", "work_items", "tile_products", "inverse_roles",
+                "s_blocks", "backsub_launches"]
+        return dict(zip(keys, (int(x) for x in v)))
 
     def sweep_once(self, radius: float = 1e4) -> float:
         ms = C.c_float(0)

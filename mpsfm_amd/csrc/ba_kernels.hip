@@ -133,6 +133,10 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 enum { MODE_FULL = 0, MODE_DIAG = 1 };
+#ifndef MPSFM_PAIR_MFMA
+#define MPSFM_PAIR_MFMA 1
+#endif
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 // Track sweep.  One workgroup per chunk of landmarks:
 //   P1  one thread per merged record: residuals, analytic Jacobians, robust weights; V_p / g_p
@@ -317,8 +321,65 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     {
       constexpr int kGroups = kThreads / kPairGroup;
       const int grp = tid / kPairGroup, row = tid - grp * kPairGroup;
+      (void)grp; (void)row;
       const int nblk = (A.dbg & 2) ? 0 : H.nblk;
       for (int b0 = 0; b0 < nblk; b0 += kGroups) {
+#if MPSFM_PAIR_MFMA
+        // The pair products on the matrix pipe: a wave takes two work items at a time and forms both 6x6 sums as the two
+        // diagonal 6x6 blocks of ONE 16x16 accumulator of v_mfma_f64_16x16x4_f64 — rows / columns 0-5 carry item A,
+        // 6-11 item B, 12-15 are idle.  The K index of a step is a PAIR: the four lane quarters (k = lane >> 4) feed
+        // four consecutive pairs of the item, one coordinate of the landmark per instruction, three instructions per four
+        // pairs.  Per pair and lane 6 doubles come from LDS instead of 21 and no multiply-add is issued on the vector
+        // pipe (the six-lanes-per-block form above is LDS-bandwidth-bound: 126 doubles read per pair).
+        {
+          const int lane = tid & 63, wave = tid >> 6;
+          const int rc = lane & 15, kq = lane >> 4;        // row (A operand) / column (B operand) of the accumulator, K slot
+          const int which = rc < 6 ? 0 : (rc < 12 ? 1 : 2);  // work item of the wave's pair this lane feeds
+          const int ab = rc - 6 * which;                   // row of Z_i / row of Z_j inside the 6x6 block
+          const int nround = min(kGroups, nblk - b0);
+          const uint32_t* ep = ents_in_lds ? s_ents : (A.ents + H.ent0);
+          for (int t = 2 * wave; t < nround; t += 2 * (kThreads / 64)) {
+            const int bi = b0 + t + which;
+            int e = 0, m = 0;
+            if (which < 2 && t + which < nround) {
+              e = A.blk_ent_start[H.blk0 + blockIdx.x + bi];
+              m = A.blk_ent_start[H.blk0 + blockIdx.x + bi + 1] - e;
+            }
+            int mmax = m;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off, 64));
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            // software pipeline: the operands of the next four pairs are requested before this group's instructions issue
+            double a0 = 0, a1 = 0, a2 = 0, c0 = 0, c1 = 0, c2 = 0;
+            auto fetch = [&](int p, double& x0, double& x1, double& x2, double& y0, double& y1, double& y2) {
+              x0 = x1 = x2 = y0 = y1 = y2 = 0.0;
+              if (p < m) {
+                const uint32_t ent = ep[e + p];
+                const double* zi = &s_W[(ent & 0xff) * kWStride + ab * 3];
+                const double* zj = &s_W[((ent >> 8) & 0xff) * kWStride + ab * 3];
+                x0 = zi[0]; x1 = zi[1]; x2 = zi[2];
+                y0 = zj[0]; y1 = zj[1]; y2 = zj[2];
+              }
+            };
+            fetch(kq, a0, a1, a2, c0, c1, c2);
+            for (int p0 = 0; p0 < mmax; p0 += 4) {
+              double n0, n1, n2, d0, d1, d2;
+              fetch(p0 + 4 + kq, n0, n1, n2, d0, d1, d2);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c0, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, c2, acc, 0, 0, 0);
+              a0 = n0; a1 = n1; a2 = n2; c0 = d0; c1 = d1; c2 = d2;
+            }
+            // accumulator element r of lane l: row (l >> 4) + 4 r, column l & 15; the two diagonal blocks go to the stage
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int orow = kq + 4 * r;
+              const int ow = orow < 6 ? 0 : (orow < 12 ? 1 : 2);
+              if (ow < 2 && ow == which && t + ow < nround) s_stage[(t + ow) * 36 + (orow - 6 * ow) * 6 + ab] = acc[r];
+            }
+          }
+        }
+#else
         const int b = b0 + grp;
         if (grp < kGroups && b < nblk) {
           // entry offsets are chunk-relative
@@ -347,6 +408,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 #pragma unroll
           for (int bb = 0; bb < 6; ++bb) s_stage[grp * 36 + row * 6 + bb] = acc[bb];
         }
+#endif
         __syncthreads();
         const int nround = min(kGroups, nblk - b0);
         if (!(A.dbg & 4)) {

@@ -43,12 +43,12 @@ void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, dou
 void launch_gmax_to_slot(double* redsc, int rank, hipStream_t);
 void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const DenseEnvelope* env, const LevelPlanDev* lp);
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const LevelPlanDev* lp);
 bool dense_level(const DenseOverlap* ov, const LevelPlanDev* lp);
 int dense_plain_max_tiles();
 int dense_inv_rows();
 size_t dense_work_doubles(int nt);
-double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const DenseEnvelope* env, const LevelPlanDev* lp);
+double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const LevelPlanDev* lp);
 
 thread_local std::string g_err;
 extern int g_dbg_flags;  // dense_chol.hip: bits 0-7 dense-solve ablations, bits 8-15 track-sweep ablations
@@ -353,9 +353,6 @@ struct mpsfm_ba_handle {
   hipStream_t stream = nullptr;
   void* comm = nullptr;  // ncclComm_t of a landmark-sharded run with use_rccl
   DenseOverlap ov;  // second stream for the dense factorisation in outer panels (MPSFM_CHOL_NB)
-  DenseEnvelope env;  // block skyline of the reduced system
-  std::vector<int32_t> env_rows_start, env_prow_start, env_rows;
-  int32_t *d_env_first = nullptr, *d_env_rows = nullptr, *d_env_prow = nullptr;
   std::vector<int32_t> sky_first;   // block skyline of S (BlockSky), host copies
   std::vector<int64_t> sky_start;
   int32_t* d_sky_first = nullptr;
@@ -425,7 +422,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
-                  h->d_env_first, h->d_env_rows, h->d_env_prow, h->d_sky_first, h->d_sky_start, h->d_sky_index,
+                  h->d_sky_first, h->d_sky_start, h->d_sky_index,
                   h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm};
   for (void* p : ptrs) cached_free(p);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
@@ -530,6 +527,29 @@ static void parallel_ranges(int64_t n, int64_t min_grain, F&& f) {
 }
 
 // Build the re-ordered, chunked record tables and upload everything.
+// the tables of the level-scheduled factorisation (h->plan) to the device
+static int upload_plan(mpsfm_ba_handle* h, int64_t nblk) {
+  const CholPlan& PL = h->plan;
+  int rc2 = 0;
+  if ((rc2 = dev_upload(&h->d_lp_items, PL.items))) return rc2;
+  if ((rc2 = dev_upload(&h->d_lp_srcs, PL.srcs))) return rc2;
+  if ((rc2 = dev_upload(&h->d_lp_rows, PL.rows))) return rc2;
+  if ((rc2 = dev_upload(&h->d_lp_struct_start, PL.struct_start))) return rc2;
+  if ((rc2 = dev_upload(&h->d_lp_struct_rows, PL.struct_rows))) return rc2;
+  if ((rc2 = dev_upload(&h->d_lp_back_cols, PL.back_cols))) return rc2;
+  if ((rc2 = dev_upload(&h->d_lp_asm, PL.asm_tiles))) return rc2;
+  LevelPlanDev& D = h->lp;
+  D.valid = PL.nt >= 1; D.use_pinv = PL.use_pinv;
+  D.d_items = h->d_lp_items; D.d_srcs = h->d_lp_srcs; D.d_rows = h->d_lp_rows;
+  D.d_struct_start = h->d_lp_struct_start; D.d_struct_rows = h->d_lp_struct_rows; D.d_back_cols = h->d_lp_back_cols;
+  D.d_asm_tiles = h->d_lp_asm; D.n_asm = (int32_t)PL.asm_tiles.size(); D.nlevels = PL.nlevels;
+  D.h_launch_start = PL.launch_start.data(); D.h_back_start = PL.back_start.data();
+  if (h->opt.verbose >= 2)
+    std::fprintf(stderr, "[mpsfm_ba] build: camera order: %s (depth %d), %d slots for %d cameras, %d tile columns in %d levels, %lld tile products, %lld inverse roles, %d blocks of S\n",
+                 PL.nd_depth < 0 ? "caller's" : "nested dissection", PL.nd_depth, PL.nslots, PL.ncv, PL.nt, PL.nlevels, (long long)PL.products, (long long)PL.roles, (int)nblk);
+  return 0;
+}
+
 static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_state* st) {
   const int nc = P->n_cams, npu = P->n_pts;
   auto t_prev = std::chrono::steady_clock::now();
@@ -1075,24 +1095,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     }
     h->sblk_blocks = nblk;
     if (int rc2 = dev_upload(&h->d_sky_index, h->sky_index)) return rc2;
-    const CholPlan& PL = h->plan;
-    int rc2 = 0;
-    if ((rc2 = dev_upload(&h->d_lp_items, PL.items))) return rc2;
-    if ((rc2 = dev_upload(&h->d_lp_srcs, PL.srcs))) return rc2;
-    if ((rc2 = dev_upload(&h->d_lp_rows, PL.rows))) return rc2;
-    if ((rc2 = dev_upload(&h->d_lp_struct_start, PL.struct_start))) return rc2;
-    if ((rc2 = dev_upload(&h->d_lp_struct_rows, PL.struct_rows))) return rc2;
-    if ((rc2 = dev_upload(&h->d_lp_back_cols, PL.back_cols))) return rc2;
-    if ((rc2 = dev_upload(&h->d_lp_asm, PL.asm_tiles))) return rc2;
-    LevelPlanDev& D = h->lp;
-    D.valid = PL.nt >= 1; D.use_pinv = PL.use_pinv;
-    D.d_items = h->d_lp_items; D.d_srcs = h->d_lp_srcs; D.d_rows = h->d_lp_rows;
-    D.d_struct_start = h->d_lp_struct_start; D.d_struct_rows = h->d_lp_struct_rows; D.d_back_cols = h->d_lp_back_cols;
-    D.d_asm_tiles = h->d_lp_asm; D.n_asm = (int32_t)PL.asm_tiles.size(); D.nlevels = PL.nlevels;
-    D.h_launch_start = PL.launch_start.data(); D.h_back_start = PL.back_start.data();
-    if (h->opt.verbose >= 2)
-      std::fprintf(stderr, "[mpsfm_ba] build: camera order: %s (depth %d), %d slots for %d cameras, %d tile columns in %d levels, %lld tile products, %lld inverse roles, %d blocks of S\n",
-                   PL.nd_depth < 0 ? "caller's" : "nested dissection", PL.nd_depth, PL.nslots, PL.ncv, PL.nt, PL.nlevels, (long long)PL.products, (long long)PL.roles, nblk);
+    if (int rc2 = upload_plan(h, nblk)) return rc2;
   } else {
     // block skyline (DenseEnvelope): which 6x6 blocks of S can be nonzero follows from the static Schur pair tables;
     // first_blk[c] = lowest camera slot that shares a landmark with slot c
@@ -1145,27 +1148,18 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       first[(size_t)ti] = f;
     }
     first[(size_t)nt] = 0;  // the right-hand-side row
-    h->env_prow_start.assign((size_t)nt + 1, 0);
-    h->env_rows_start.assign((size_t)std::max(nt, 1), 0);
-    std::vector<int32_t> prow;
-    h->env_rows.clear();
-    for (int j = -1; j <= nt - 2; ++j) {
-      h->env_prow_start[(size_t)j + 1] = (int32_t)prow.size();
-      for (int ti = j + 1; ti <= nt; ++ti) if (first[(size_t)ti] <= j + 1) prow.push_back(ti);
-      if (j >= 0) {
-        h->env_rows_start[(size_t)j] = (int32_t)h->env_rows.size();
-        for (int ti = j + 1; ti <= nt; ++ti) if (first[(size_t)ti] <= j) h->env_rows.push_back(ti);
-      }
+    // the factorisation plan of the skyline in the caller's order: tile (ti, tj) can be nonzero for tj >= first[ti]
+    {
+      std::vector<uint8_t> pat((size_t)nt * (size_t)nt, 0);
+      for (int ti = 0; ti < nt; ++ti)
+        for (int tj = first[(size_t)ti]; tj < ti; ++tj) pat[(size_t)ti * nt + tj] = 1;
+      CholPlan& PL = h->plan;
+      PL.ncv = ncv; PL.nslots = ncv; PL.n = n; PL.nd_depth = -1;
+      PL.slot_of_nat = h->nat_slot; PL.nat_of_slot = h->nat_slot;
+      plan_from_pattern(pat, nt, nt <= dense_plain_max_tiles() && !(std::getenv("MPSFM_CHOL_INVERSE") && std::atoi(std::getenv("MPSFM_CHOL_INVERSE")) == 0),
+                        dense_inv_rows(), PL);
+      if (int rc2 = upload_plan(h, h->sblk_blocks)) return rc2;
     }
-    h->env_prow_start[(size_t)nt] = (int32_t)prow.size();
-    if (nt >= 1) h->env_rows_start[(size_t)nt - 1] = (int32_t)h->env_rows.size();
-    int rc2 = 0;
-    if ((rc2 = dev_upload(&h->d_env_first, first))) return rc2;
-    if ((rc2 = dev_upload(&h->d_env_rows, h->env_rows))) return rc2;
-    if ((rc2 = dev_upload(&h->d_env_prow, prow))) return rc2;
-    h->env.valid = nt >= 1;
-    h->env.d_first = h->d_env_first; h->env.d_rows = h->d_env_rows; h->env.d_prow = h->d_env_prow;
-    h->env.h_rows_start = h->env_rows_start.data(); h->env.h_prow_start = h->env_prow_start.data(); h->env.h_rows = h->env_rows.data();
     if (h->opt.verbose >= 2) {
       int64_t inside = 0;
       for (int ti = 0; ti < nt; ++ti) inside += ti - first[(size_t)ti] + 1;
@@ -1245,6 +1239,9 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if (const char* e = std::getenv("MPSFM_CHOL_OVERLAP")) h->ov.overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("MPSFM_CHOL_INVERSE")) h->ov.no_inverse = std::atoi(e) == 0;
   if (const char* e = std::getenv("MPSFM_CHOL_LEVEL")) h->ov.no_level = std::atoi(e) == 0;
+  // a large reduced system without exploitable structure (every camera shares landmarks with most others): the
+  // outer-panel path with its LDS-staged 64x64 trailing update moves fewer bytes per flop than one workgroup per tile
+  else if (h->nt > dense_plain_max_tiles() && (double)h->plan.products > 0.5 * (double)h->nt * h->nt * h->nt / 6.0) h->ov.no_level = true;
   if (h->nt > 64 || h->ov.nb > 0) {
     HIP_TRY(pooled_stream(&h->ov.s2));
     for (auto& e : h->ov.evF) HIP_TRY(pooled_event(&e, false));
@@ -1365,12 +1362,12 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
   if (h->n > 0) {
     // the level-scheduled factorisation without inverse accumulators only touches the tiles of its plan
     const bool level = dense_level(&h->ov, &h->lp);
-    double* pinv = dense_pinv(h->d_dwork, h->nt, &h->ov, &h->env, &h->lp);
+    double* pinv = dense_pinv(h->d_dwork, h->nt, &h->ov, &h->lp);
     const bool listed = level && !pinv;
     AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius,
                     h->opt.min_lm_diagonal, h->opt.max_lm_diagonal, h->d_A, pinv, listed ? h->lp.d_asm_tiles : nullptr, listed ? h->lp.n_asm : 0};
     launch_assemble(as, s);
-    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->env, &h->lp);
+    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->lp);
   }
   return 0;
 }
@@ -1736,6 +1733,16 @@ int mpsfm_ba_eval_cost(mpsfm_ba_handle* h, double* cost_reproj, double* cost_dep
   return 0;
 }
 
+int mpsfm_ba_dense_plan(mpsfm_ba_handle* h, int64_t info[10]) {
+  if (!h || !info) return fail(MPSFM_EINVAL, "handle or info is NULL");
+  const CholPlan& P = h->plan;
+  const bool level = dense_level(&h->ov, &h->lp);
+  const bool pinv = level && dense_pinv(h->d_dwork, h->nt, &h->ov, &h->lp) != nullptr;
+  const int64_t v[10] = {h->ncv, h->nt, level ? P.nlevels : h->nt, P.nd_depth, pinv ? 1 : 0, (int64_t)P.items.size(), P.products, P.roles, h->sblk_blocks,
+                         pinv ? 2 : (level ? P.nlevels : (h->nt + 3) / 4 + 1)};
+  for (int i = 0; i < 10; ++i) info[i] = v[i];
+  return 0;
+}
 int mpsfm_ba_reduced_dim(mpsfm_ba_handle* h) { return h ? h->n_user : MPSFM_EINVAL; }
 
 int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms) {

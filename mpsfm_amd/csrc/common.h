@@ -283,20 +283,6 @@ struct DenseOverlap {
   hipEvent_t evB[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
-// Block skyline of the reduced camera system in 32 x 32 tiles, static per problem (dense_chol.hip): tile (ti, tj) can be
-// nonzero in S and in its Cholesky factor only for tj >= first[ti].  Per factorisation step j the rows that take part:
-//   rows(j)  = { ti > j : first[ti] <= j }  (L(ti, j) != 0; always ends with the right-hand-side row nt)
-//   prow(j)  = { ti >= j+1 : first[ti] <= j+1 }  (tiles of the panel column j+1 inside the skyline), j = -1 .. nt-2
-struct DenseEnvelope {
-  bool valid = false;
-  const int32_t* d_first = nullptr;  // [nt+1]
-  const int32_t* d_rows = nullptr;   // concatenated rows(j), j = 0 .. nt-2
-  const int32_t* d_prow = nullptr;   // concatenated prow(j), j = -1 .. nt-2
-  const int32_t* h_rows_start = nullptr;  // host: [nt]   offsets of rows(j)   (entry nt-1 = total)
-  const int32_t* h_prow_start = nullptr;  // host: [nt+1] offsets of prow(j-1) (entry nt = total)
-  const int32_t* h_rows = nullptr;        // host copy of the row lists (the launcher looks at rows(j)[0])
-};
-
 // Device tables of the level-scheduled factorisation (chol_plan.h), static per handle.
 struct LevelPlanDev {
   bool valid = false, use_pinv = false;

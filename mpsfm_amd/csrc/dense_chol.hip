@@ -335,27 +335,28 @@ extern "C" int mpsfm_debug_set_chol_trace(long long* dev_buf) {
 }
 #define MPSFM_STAMP(k) do { if (trace_on && lane == 0) tr[(k)] = wall_clock64(); } while (0)
 
-// One step of the right-looking factorisation, two waves per tile.  j = -1: factor tile column 0 only.
-//   trailing tile (tk > j+1):  A[ti][tk] -= L[ti][j] L[tk][j]^T, one 16-row half per wave.
-//   panel tile (tk == j+1):    wave 0 re-derives the updated diagonal tile and factors it in registers,
-//                              wave 1 updates the workgroup's own tile meanwhile and then solves it
-//                              against the factor (X L^-T); the workgroup that owns the diagonal tile
-//                              stores L and L^-T (kept for the back substitution).
-// Outer panels (large matrices): c0 is the first tile column whose L is applied to a trailing tile in this
+// Dense outer-panel path (reduced systems without exploitable structure, MPSFM_CHOL_NB): one step of the right-looking
+// factorisation, four waves per tile.  j = -1: factor tile column 0 only.
+//   trailing tile (tk > j+1):  A[ti][tk] -= L[ti][j] L[tk][j]^T, one quadrant per wave.
+//   panel tile (tk == j+1):    every workgroup re-derives the updated diagonal tile; wave 0 factors the stacked
+//                              [D; X] (stacked_panel); the workgroup that owns the diagonal tile stores L^-T
+//                              (kept for the back substitution).
+// c0 is the first tile column whose L is applied to a trailing tile in this
 // launch (c0 == j: the plain right-looking step), tk_max the last tile column this launch touches, and
 //   kStepNoOwnUpdate  the panel column j+1 has already received column j (first step of an outer panel),
 //   kStepBig          no factorisation: every tile (ti, tk), j < tk <= tk_max, gets columns c0..j at once
 //                     (one load and one store of the tile for a rank-32*(j-c0+1) update).
-constexpr int kStepNoOwnUpdate = 1, kStepBig = 2, kStepEnv = 4;
-// Inverse propagation (plain path only, Pinv != NULL).  The back substitution y = L^-T z is a chain of nt dependent
-// tile solves — ten launches of ~10 us at nt = 38.  Instead the steps also build, in the shadow of their
-// latency-bound panel factorisation, the accumulators  P(i,k) = sum_{j=k}^{i-1} L(i,j) X(j,k)  of the inverse
-// X = L^-1  (X(k,k) = L(k,k)^-1, X(i,k) = -L(i,i)^-1 P(i,k)), after which
+constexpr int kStepNoOwnUpdate = 1, kStepBig = 2;
+// Inverse propagation (level-scheduled path up to kPlainMaxTiles tile columns, Pinv != NULL).  The back substitution
+// y = L^-T z is another chain of dependent tile solves, one launch per level.  Instead the launches also build, in the
+// shadow of their latency-bound panel factorisation, the accumulators  P(i,k) = sum_{j=k}^{i-1} L(i,j) X(j,k)  of the
+// inverse X = L^-1  (X(k,k) = L(k,k)^-1, X(i,k) = -L(i,i)^-1 P(i,k)), after which
 //   y_k = w_k - sum_{i>k} P(i,k)^T w_i,   w_i = L(i,i)^-T z_i
-// is two launches.  Launch j uses column j of L and L(j,j)^-1, both final since launch j-1:
-//   role (i, k), j < i < nt, k <= j:   P(i,k) += L(i,j) X(j,k),  X(j,k) recomputed from P(j,k) (final: it last
-//   changed in launch j-1), so no workgroup reads what another one writes in the same launch.
-// Roles are the blocks with blockIdx.y >= cols.
+// is two launches.  The launch after column j was factored uses column j of L and L(j,j)^-1, both final:
+//   role (j, k), k in the subtree of j (X(j,k) is zero elsewhere):   P(i,k) += L(i,j) X(j,k) for the rows i of struct(j),
+//   X(j,k) recomputed from P(j,k) (final: its contributions come from descendants of j, whose roles ran in earlier
+//   launches), so no workgroup reads what another one writes in the same launch; two columns of one level have disjoint
+//   subtrees, so their roles never write the same accumulator.
 #ifndef MPSFM_INV_ROWS
 #define MPSFM_INV_ROWS 2
 #endif
@@ -412,55 +413,16 @@ __device__ __forceinline__ void inv_role(const double* A, const double* LinvT, d
   }
 }
 
-struct StepEnv {  // the skyline rows of this step (kStepEnv), see DenseEnvelope
-  const int32_t* first; const int32_t* rows; const int32_t* prow;
-  int nr, np;
-};
-
 __global__ __launch_bounds__(kStepThreads) void k_chol_step(double* A, double* LinvT, int nt, int j, int* fail, int dbg, int c0, int tk_max,
-                                                            int mode, double* Pinv, int cols, StepEnv E) {
+                                                            int mode) {
   __shared__ double s_T[kTile][kTile + 1];
   __shared__ double s_X[kTile][kTile + 1];
   __shared__ __attribute__((aligned(16))) double s_Lt[kTile * kTile];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mi = wave & 1, ni = wave >> 1;  // this wave's quadrant
   if (dbg & 16) return;  // ablation: the launch chain alone
-  int tk, ti;
-  bool upd_D = true, upd_X = true;  // whether column j reaches the diagonal tile / this workgroup's tile (skyline)
-  if (mode & kStepEnv) {
-    // plain step inside the block skyline, 1-D grid without idle workgroups: [panel tiles | inverse roles | trailing tiles]
-    const int off = (E.nr > 0 && E.rows[0] == j + 1) ? 1 : 0;  // row j+1 belongs to the panel, not to the trailing block
-    const int a = E.nr - off;                                   // trailing rows (the last one is the right-hand side)
-    const int ntrail = a > 0 ? a * (a + 1) / 2 : 0;
-    const int nrr = E.nr - 1;                                   // role rows: all of rows(j) but the right-hand side
-    const int ngrp = (nrr + kInvRows - 1) / kInvRows;
-    const int nroles = (Pinv && j >= 0 && nrr > 0) ? ngrp * (j + 1) : 0;
-    int q = blockIdx.x;
-    if (q < E.np) {
-      tk = j + 1; ti = E.prow[q];
-      upd_D = j >= 0 && E.first[tk] <= j;
-      upd_X = upd_D && E.first[ti] <= j;
-    } else if (q < E.np + nroles) {
-      const int role = q - E.np;
-      if (dbg & 8) return;  // dbg 8: dispatch the roles, do nothing
-      const int g = role % ngrp;
-      inv_role(A, LinvT, Pinv, nt, j, E.rows + g * kInvRows, min(kInvRows, nrr - g * kInvRows), role / ngrp, s_T, s_Lt);
-      return;
-    } else {
-      q -= E.np + nroles;
-      if (q >= ntrail) return;
-      int r = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-      while (r * (r + 1) / 2 > q) --r;
-      while ((r + 1) * (r + 2) / 2 <= q) ++r;
-      const int c = q - r * (r + 1) / 2;
-      tk = E.rows[off + c]; ti = E.rows[off + r];
-      if (tk >= nt) return;  // (rhs, rhs) is not a tile
-    }
-  } else {
-    tk = j + 1 + blockIdx.y;
-    ti = j + 1 + blockIdx.x;
-    if (ti < tk || tk >= nt || ti > nt || tk > tk_max) return;
-  }
+  const int tk = j + 1 + blockIdx.y, ti = j + 1 + blockIdx.x;
+  if (ti < tk || tk >= nt || ti > nt || tk > tk_max) return;
   double* C = A + lt_tile(ti, tk) * kTileElems;
   if (tk != j + 1 || (mode & kStepBig)) {
     // trailing tile: A[ti][tk] -= sum_c L[ti][c] L[tk][c]^T, one quadrant per wave
@@ -488,13 +450,13 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_step(double* A, double* L
     v4d dacc, xacc;
     quad_load(A + lt_tile(tk, tk) * kTileElems, kTile, lane, mi, ni, dacc);
     if (!diag) quad_load(C, kTile, lane, mi, ni, xacc);
-    if (own_update && upd_D) {
+    if (own_update) {
       const double* Lk = A + lt_tile(tk, j) * kTileElems;
       double am[8], bn[8];
       quad_operand(Lk, lane, mi, am);
       quad_operand(Lk, lane, ni, bn);
       quad_gemm_sub(am, bn, dacc);
-      if (!diag && upd_X) {
+      if (!diag) {
         quad_operand(A + lt_tile(ti, j) * kTileElems, lane, mi, am);
         quad_gemm_sub(am, bn, xacc);
       }
@@ -838,8 +800,7 @@ static int dense_panel_width(int nt, const DenseOverlap* ov) {
   return (ov && ov->nb > 0) ? ov->nb : ((nt <= kPlainMaxTiles) ? nt : 8);
 }
 // the accumulators of the inverse propagation, or NULL when this solve does not use them (outer panels, switched off)
-double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const DenseEnvelope* env, const LevelPlanDev* lp) {
-  (void)env;
+double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const LevelPlanDev* lp) {
   if (nt <= 0 || nt > kPlainMaxTiles || (ov && (ov->no_inverse || ov->nb > 0))) return nullptr;
   if (dense_level(ov, lp) && !lp->use_pinv) return nullptr;
   return work + (size_t)nt * kTileElems + 2 * (size_t)nt * kTile + ((size_t)nt + 1) * kTileElems;
@@ -848,15 +809,13 @@ double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const DenseEnve
 // ov (may be NULL): a second stream and events.  With it the update of an outer panel is split: the tile
 // columns of the NEXT panel are updated on the main stream (the factorisation needs them next), the columns
 // beyond run on the second stream under the next panel's factorisation steps.
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov, const DenseEnvelope* env,
-                        const LevelPlanDev* lp) {
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov, const LevelPlanDev* lp) {
   if (nt <= 0) return;
   double* LinvT = work;
   double* zbuf = work + (size_t)nt * kTileElems;
   double* wbuf = zbuf + (size_t)nt * kTile;
-  const StepEnv no_env{nullptr, nullptr, nullptr, 0, 0};
   if (dense_level(ov, lp)) {
-    double* Pinv = dense_pinv(work, nt, ov, env, lp);
+    double* Pinv = dense_pinv(work, nt, ov, lp);
     LevelArgs G{A, LinvT, Pinv, nullptr, lp->d_srcs, lp->d_rows, fail, nt, g_dbg_flags};
     for (int l = 0; l < lp->nlevels; ++l) {
       const int grid = lp->h_launch_start[l + 1] - lp->h_launch_start[l];
@@ -877,42 +836,6 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
     }
     return;
   }
-  if (env && env->valid && !(ov && ov->nb > 0)) {
-    // Block-skyline factorisation: one launch per tile column, every launch a 1-D grid over the tiles that can be
-    // nonzero (DenseEnvelope).  What Ceres gets from its sparse Cholesky (reference bundle_adjustment.py:288,
-    // SPARSE_SCHUR): with cameras that only share landmarks with their neighbours most of S and of L is structurally
-    // zero — at C3 232 of 741 tiles are inside the skyline and the trailing updates shrink 14-fold.
-    double* Pinv = dense_pinv(work, nt, ov, env, lp);
-    for (int j = -1; j <= nt - 2; ++j) {
-      StepEnv E;
-      E.first = env->d_first;
-      E.prow = env->d_prow + env->h_prow_start[j + 1];
-      E.np = env->h_prow_start[j + 2] - env->h_prow_start[j + 1];
-      E.rows = nullptr; E.nr = 0;
-      int grid = E.np;
-      if (j >= 0) {
-        E.rows = env->d_rows + env->h_rows_start[j];
-        E.nr = env->h_rows_start[j + 1] - env->h_rows_start[j];
-        const int off = (E.nr > 0 && env->h_rows[env->h_rows_start[j]] == j + 1) ? 1 : 0;
-        const int a = E.nr - off, nrr = E.nr - 1;
-        grid += (a > 0 ? a * (a + 1) / 2 : 0) + ((Pinv && nrr > 0) ? ((nrr + kInvRows - 1) / kInvRows) * (j + 1) : 0);
-      }
-      if (grid <= 0) continue;
-      hipLaunchKernelGGL(k_chol_step, dim3(grid), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, nt - 1,
-                         kStepEnv | (j < 0 ? kStepNoOwnUpdate : 0), Pinv, 1, E);
-    }
-    if (Pinv) {
-      hipLaunchKernelGGL(k_inv_w, dim3(nt), dim3(64), 0, s, A, LinvT, nt, n, wbuf, y);
-      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, Pinv, wbuf, nt, n, y);
-      return;
-    }
-    hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
-    for (int t1 = nt; t1 > 0; t1 -= kBsG) {
-      const int t0 = t1 - kBsG > 0 ? t1 - kBsG : 0;
-      hipLaunchKernelGGL(k_backsub_group, dim3(t0 > 0 ? t0 : 1), dim3(256), 0, s, A, LinvT, nt, n, t0, t1, zbuf, y);
-    }
-    return;
-  }
   // Outer panels of NB tile columns.  Inside a panel the plain right-looking steps run on the panel's
   // columns only; the tiles to the right then receive the whole panel in one launch (their load / store is
   // paid once per NB columns).  Up to 64 tile columns the matrix is one panel: exactly the plain algorithm.
@@ -925,17 +848,16 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
     const int pend = (p0 + NB - 1 < nt - 1) ? p0 + NB - 1 : nt - 1;
     // factor column p0 (its tiles already hold every earlier column); ti in [p0, nt]
     hipLaunchKernelGGL(k_chol_step, dim3(nt - p0 + 1, 1), dim3(kStepThreads), 0, s, A, LinvT, nt, p0 - 1, fail, g_dbg_flags, p0 - 1, p0,
-                       kStepNoOwnUpdate, (double*)nullptr, 1, no_env);
+                       kStepNoOwnUpdate);
     for (int j = p0; j <= pend - 1; ++j) {  // apply column j to columns (j, pend], factor column j+1; ti in [j+1, nt]
       const int rows = nt - j, cols = pend - j;
-      hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0,
-                         (double*)nullptr, cols, no_env);
+      hipLaunchKernelGGL(k_chol_step, dim3(rows, cols), dim3(kStepThreads), 0, s, A, LinvT, nt, j, fail, g_dbg_flags, j, pend, 0);
     }
     if (pend >= nt - 1) break;
     // columns (pend, nt-1] receive the panel p0..pend; ti in [pend+1, nt]
     if (!big_kernel) {
       hipLaunchKernelGGL(k_chol_step, dim3(nt - pend, nt - 1 - pend), dim3(kStepThreads), 0, s, A, LinvT, nt, pend, fail, g_dbg_flags, p0, nt - 1,
-                         kStepBig, (double*)nullptr, nt - 1 - pend, no_env);
+                         kStepBig);
     } else if (!overlap) {
       launch_big(A, nt, pend, p0, pend + 1, nt - 1, s);
     } else {

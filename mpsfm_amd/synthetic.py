@@ -280,3 +280,23 @@ def local_window(prob: BAProblem, window_cams, ref_cam: int, max_track: int = 15
         depth_loss_type=prob.depth_loss_type,
     )
     return local, cam_ids, pt_ids
+
+
+def shuffle_cameras(prob: BAProblem, seed: int = 0) -> tuple[BAProblem, np.ndarray]:
+    """The same problem with its cameras in a random order (an unordered photo collection instead of a sequence).
+    Returns (problem, perm) with new camera i = old camera perm[i]; the gauge cameras keep their roles."""
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(prob.n_cams)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(prob.n_cams)
+    q = prob.copy()
+    q.cam_quat, q.cam_t = prob.cam_quat[perm].copy(), prob.cam_t[perm].copy()
+    q.cam_intr_idx, q.pose_const = prob.cam_intr_idx[perm].copy(), prob.pose_const[perm].copy()
+    q.obs_cam = inv[prob.obs_cam].astype(np.int32)
+    if prob.n_dobs:
+        q.dobs_cam = inv[prob.dobs_cam].astype(np.int32)
+    if prob.shift_logscale is not None:
+        q.shift_logscale = prob.shift_logscale[perm].copy()
+    if prob.gauge_axis_cam >= 0:
+        q.gauge_axis_cam = int(inv[prob.gauge_axis_cam])
+    return q, perm
