@@ -539,7 +539,7 @@ static int upload_plan(mpsfm_ba_handle* h, int64_t nblk) {
   if ((rc2 = dev_upload(&h->d_lp_back_cols, PL.back_cols))) return rc2;
   if ((rc2 = dev_upload(&h->d_lp_asm, PL.asm_tiles))) return rc2;
   LevelPlanDev& D = h->lp;
-  D.valid = PL.nt >= 1; D.use_pinv = PL.use_pinv;
+  D.valid = PL.nt >= 1 && PL.nlevels >= 1; D.use_pinv = PL.use_pinv;
   D.d_items = h->d_lp_items; D.d_srcs = h->d_lp_srcs; D.d_rows = h->d_lp_rows;
   D.d_struct_start = h->d_lp_struct_start; D.d_struct_rows = h->d_lp_struct_rows; D.d_back_cols = h->d_lp_back_cols;
   D.d_asm_tiles = h->d_lp_asm; D.n_asm = (int32_t)PL.asm_tiles.size(); D.nlevels = PL.nlevels;

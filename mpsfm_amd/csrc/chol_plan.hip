@@ -14,8 +14,9 @@ namespace {
 
 constexpr int kSegAlign = 16;    // slots per alignment unit: 16 cameras x 6 columns = 3 tiles
 constexpr int kMoveUpMax = 4;    // a segment with this many cameras beyond a multiple of 16 hands them to its parent instead of padding
-constexpr int kMinLeaf = 48;     // no dissection below this many cameras
+constexpr int kMinLeaf = 32;     // no dissection below this many cameras
 constexpr int kMinBfsLevels = 5;
+constexpr double kMaxPlanProducts = 2.0e7;  // tile products beyond which no item table is built (~0.5 GB of tables)
 
 using Mask = std::vector<uint64_t>;
 
@@ -243,6 +244,17 @@ void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, i
     for (int i = j + 1; i <= nt; ++i) if (bit(j, i)) P.struct_rows.push_back(i);
     P.struct_start[(size_t)j + 1] = (int32_t)P.struct_rows.size();
   }
+  // a reduced system without exploitable structure would need a table of ~nt^3/6 tile products: leave the item tables
+  // empty (nlevels = 0) and let the caller fall back to the dense outer-panel path
+  {
+    double prod = 0.0;
+    for (int j = 0; j < nt; ++j) { const double sj = (double)(P.struct_start[(size_t)j + 1] - P.struct_start[(size_t)j]); prod += 0.5 * sj * (sj + 1.0); }
+    if (prod > kMaxPlanProducts) {
+      P.products = (int64_t)prod; P.nlevels = 0; P.est_us = 1e30;
+      P.launch_start.assign(1, 0); P.back_start.assign(1, 0);
+      return;
+    }
+  }
   auto rows_of = [&](int j) { return std::make_pair(P.struct_rows.data() + P.struct_start[(size_t)j], P.struct_rows.data() + P.struct_start[(size_t)j + 1]); };
   auto lt = [](int64_t ti, int64_t tj) { return (int32_t)(ti * (ti + 1) / 2 + tj); };
   for (int j = 0; j < nt; ++j) {
@@ -322,8 +334,8 @@ void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, i
 
 void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_tiles, int inv_rows, CholPlan& best) {
   int dmax = -1;
-  for (int s = g.n; s >= 2 * kMinLeaf; s /= 2) ++dmax;  // leaves of at least kMinLeaf cameras
-  dmax = std::min(dmax + 1, 5);
+  for (int s = g.n; s >= kMinLeaf; s /= 2) ++dmax;  // parts of at least kMinLeaf cameras are worth cutting again
+  dmax = std::min(dmax, 5);
   bool have = false;
   for (int d = -1; d <= (forced ? -1 : dmax); ++d) {
     const int depth = forced ? forced_depth : d;

@@ -205,3 +205,49 @@ def test_dissection_shortens_the_chain_of_an_orbit():
     assert ident["nlevels"] == ident["nt"] == 38
     assert auto["nd_depth"] >= 1 and auto["nlevels"] <= 24
     assert auto["products"] <= 2 * ident["products"]
+
+
+def _graph(kind, n, seed=0):
+    rng = np.random.default_rng(seed)
+    adj = np.zeros((n, n), np.uint8)
+    if kind == "path":
+        for i in range(n - 1):
+            adj[i, i + 1] = 1
+    elif kind == "star":
+        adj[0, 1:] = 1
+    elif kind == "complete":
+        adj[:] = 1
+    elif kind == "grid":  # cameras on a lattice (aerial blocks): neighbours in both directions
+        w = int(np.sqrt(n))
+        for i in range(n):
+            for d in (1, w, w + 1, w - 1):
+                j = i + d
+                if j < n and not (d == 1 and j % w == 0):
+                    adj[i, j] = 1
+    elif kind == "random":
+        m = rng.random((n, n)) < 6.0 / n
+        adj[m] = 1
+    elif kind == "isolated":  # a sequence, a clique and cameras that share nothing with anyone
+        for i in range(40):
+            for d in (1, 2, 3):
+                if i + d < 40:
+                    adj[i, i + d] = 1
+        adj[50:62, 50:62] = 1
+    adj = np.maximum(adj, adj.T)
+    np.fill_diagonal(adj, 0)
+    return adj
+
+
+@pytest.mark.parametrize("kind,n", [("path", 90), ("star", 70), ("complete", 40), ("grid", 144), ("random", 100), ("isolated", 75)])
+@pytest.mark.parametrize("depth", [-2, 3])
+def test_plan_on_other_camera_graphs(kind, n, depth):
+    adj = _graph(kind, n, seed=n)
+    P = _plan(adj, depth=depth)
+    S, rhs = reduced_system(adj, P, seed=3)
+    y = interpret(P, S, rhs, np.random.default_rng(9))
+    ref = np.linalg.solve(S, rhs)
+    assert np.abs(y - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    if kind == "path" and depth == -2:
+        assert P["nlevels"] < P["nt"]  # a chain dissects into chains
+    if kind == "complete":
+        assert P["nlevels"] == P["nt"]  # nothing to gain: one dense chain, whatever the order
