@@ -66,7 +66,7 @@ def mfma_summary(d):
     dur = defaultdict(dict)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if not any(t in k for t in ("k_chol_step", "k_big_update", "k_backsub_group")):
+        if not any(t in k for t in ("k_chol_level", "k_back_level", "k_chol_step", "k_big_update", "k_backsub_group")):
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
