@@ -10,6 +10,8 @@
 //   k_update_sweep  back-substitution of the landmark steps, model cost change, candidate
 //                   landmarks and the candidate cost in one pass over the same chunks.
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace mpsfm {
 
@@ -133,10 +135,7 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 enum { MODE_FULL = 0, MODE_DIAG = 1 };
-#ifndef MPSFM_PAIR_MFMA
-#define MPSFM_PAIR_MFMA 1
-#endif
-typedef double v4d __attribute__((ext_vector_type(4)));
+
 
 // Track sweep.  One workgroup per chunk of landmarks:
 //   P1  one thread per merged record: residuals, analytic Jacobians, robust weights; V_p / g_p
@@ -149,6 +148,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 //   P4  flush the per-camera LDS accumulators, write the chunk partials
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
+  if (lm_over(A.ctl)) return;
+  const double lm_radius = A.ctl ? lm_radius_of(A.ctl) : A.radius;
   __shared__ __attribute__((aligned(16))) double s_W[kObsMax * kWStride];
   __shared__ __attribute__((aligned(16))) double s_V[kPtsMax * 6];
   __shared__ double s_g[kPtsMax * 3];
@@ -269,9 +270,9 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       double V[6], Vi[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) V[k] = s_V[tid * 6 + k];
-      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
-      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
-      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
+      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / lm_radius;
+      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / lm_radius;
+      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / lm_radius;
       // Vi <- F = L^-1 of V + D = L L^T: the Schur products become Z Z'^T with Z = W F^T (see spd3_inv_factor)
       if (!spd3_inv_factor(V, Vi)) {
         my_bad = 1;
@@ -321,65 +322,8 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     {
       constexpr int kGroups = kThreads / kPairGroup;
       const int grp = tid / kPairGroup, row = tid - grp * kPairGroup;
-      (void)grp; (void)row;
       const int nblk = (A.dbg & 2) ? 0 : H.nblk;
       for (int b0 = 0; b0 < nblk; b0 += kGroups) {
-#if MPSFM_PAIR_MFMA
-        // The pair products on the matrix pipe: a wave takes two work items at a time and forms both 6x6 sums as the two
-        // diagonal 6x6 blocks of ONE 16x16 accumulator of v_mfma_f64_16x16x4_f64 — rows / columns 0-5 carry item A,
-        // 6-11 item B, 12-15 are idle.  The K index of a step is a PAIR: the four lane quarters (k = lane >> 4) feed
-        // four consecutive pairs of the item, one coordinate of the landmark per instruction, three instructions per four
-        // pairs.  Per pair and lane 6 doubles come from LDS instead of 21 and no multiply-add is issued on the vector
-        // pipe (the six-lanes-per-block form above is LDS-bandwidth-bound: 126 doubles read per pair).
-        {
-          const int lane = tid & 63, wave = tid >> 6;
-          const int rc = lane & 15, kq = lane >> 4;        // row (A operand) / column (B operand) of the accumulator, K slot
-          const int which = rc < 6 ? 0 : (rc < 12 ? 1 : 2);  // work item of the wave's pair this lane feeds
-          const int ab = rc - 6 * which;                   // row of Z_i / row of Z_j inside the 6x6 block
-          const int nround = min(kGroups, nblk - b0);
-          const uint32_t* ep = ents_in_lds ? s_ents : (A.ents + H.ent0);
-          for (int t = 2 * wave; t < nround; t += 2 * (kThreads / 64)) {
-            const int bi = b0 + t + which;
-            int e = 0, m = 0;
-            if (which < 2 && t + which < nround) {
-              e = A.blk_ent_start[H.blk0 + blockIdx.x + bi];
-              m = A.blk_ent_start[H.blk0 + blockIdx.x + bi + 1] - e;
-            }
-            int mmax = m;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off, 64));
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            // software pipeline: the operands of the next four pairs are requested before this group's instructions issue
-            double a0 = 0, a1 = 0, a2 = 0, c0 = 0, c1 = 0, c2 = 0;
-            auto fetch = [&](int p, double& x0, double& x1, double& x2, double& y0, double& y1, double& y2) {
-              x0 = x1 = x2 = y0 = y1 = y2 = 0.0;
-              if (p < m) {
-                const uint32_t ent = ep[e + p];
-                const double* zi = &s_W[(ent & 0xff) * kWStride + ab * 3];
-                const double* zj = &s_W[((ent >> 8) & 0xff) * kWStride + ab * 3];
-                x0 = zi[0]; x1 = zi[1]; x2 = zi[2];
-                y0 = zj[0]; y1 = zj[1]; y2 = zj[2];
-              }
-            };
-            fetch(kq, a0, a1, a2, c0, c1, c2);
-            for (int p0 = 0; p0 < mmax; p0 += 4) {
-              double n0, n1, n2, d0, d1, d2;
-              fetch(p0 + 4 + kq, n0, n1, n2, d0, d1, d2);
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c0, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, c2, acc, 0, 0, 0);
-              a0 = n0; a1 = n1; a2 = n2; c0 = d0; c1 = d1; c2 = d2;
-            }
-            // accumulator element r of lane l: row (l >> 4) + 4 r, column l & 15; the two diagonal blocks go to the stage
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int orow = kq + 4 * r;
-              const int ow = orow < 6 ? 0 : (orow < 12 ? 1 : 2);
-              if (ow < 2 && ow == which && t + ow < nround) s_stage[(t + ow) * 36 + (orow - 6 * ow) * 6 + ab] = acc[r];
-            }
-          }
-        }
-#else
         const int b = b0 + grp;
         if (grp < kGroups && b < nblk) {
           // entry offsets are chunk-relative
@@ -408,7 +352,6 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 #pragma unroll
           for (int bb = 0; bb < 6; ++bb) s_stage[grp * 36 + row * 6 + bb] = acc[bb];
         }
-#endif
         __syncthreads();
         const int nround = min(kGroups, nblk - b0);
         if (!(A.dbg & 4)) {
@@ -477,6 +420,8 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 // Update sweep: y_p = -(V+D)^-1 (g_p + W^T y_c), model cost change, candidate landmarks, candidate
 // cost.  Recomputes the linearisation (cheaper than storing 240 B per record in HBM).
 __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
+  if (lm_over(A.ctl)) return;
+  const double lm_radius = A.ctl ? lm_radius_of(A.ctl) : A.radius;
   __shared__ double s_V[kPtsMax * 6];
   __shared__ double s_g[kPtsMax * 3];   // g_p + W^T y_c, then y_p
   __shared__ double s_x2[kPtsMax * 3];  // candidate landmark
@@ -547,9 +492,9 @@ __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
       double V[6], Vi[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) V[k] = s_V[tid * 6 + k];
-      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
-      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
-      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
+      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / lm_radius;
+      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / lm_radius;
+      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / lm_radius;
       if (!spd3_inverse(V, Vi)) {
         ok = false;
       } else {
@@ -626,6 +571,8 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* s_buf /* N * 4
 // records; W goes to an HBM scratch; U / g_c / Schur blocks are added to the reduced system directly.
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_long_track_sweep(SweepArgs A) {
+  if (lm_over(A.ctl)) return;
+  const double lm_radius = A.ctl ? lm_radius_of(A.ctl) : A.radius;
   __shared__ double s_buf[9 * 4];
   __shared__ double s_vi[9];
   const int tid = threadIdx.x;
@@ -687,9 +634,9 @@ __global__ __launch_bounds__(kThreads) void k_long_track_sweep(SweepArgs A) {
     double Vi[6] = {0, 0, 0, 0, 0, 0}, vg[3] = {0, 0, 0};
     if (pvar) {
       double V[6] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]};
-      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
-      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
-      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
+      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / lm_radius;
+      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / lm_radius;
+      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / lm_radius;
       if (!spd3_inverse(V, Vi)) { my_bad += 1.0; for (int k = 0; k < 6; ++k) Vi[k] = 0.0; }
       sym3_mul(Vi, acc[6], acc[7], acc[8], vg);
       my_gmax = fmax(fabs(acc[6] / psc[0]), fmax(fabs(acc[7] / psc[1]), fabs(acc[8] / psc[2])));
@@ -756,6 +703,8 @@ __global__ __launch_bounds__(kThreads) void k_long_track_sweep(SweepArgs A) {
 
 // Update sweep of one long-track landmark (see k_update_sweep).
 __global__ __launch_bounds__(kThreads) void k_long_update_sweep(SweepArgs A) {
+  if (lm_over(A.ctl)) return;
+  const double lm_radius = A.ctl ? lm_radius_of(A.ctl) : A.radius;
   __shared__ double s_buf[9 * 4];
   __shared__ double s_b[6];
   const int tid = threadIdx.x;
@@ -801,9 +750,9 @@ __global__ __launch_bounds__(kThreads) void k_long_update_sweep(SweepArgs A) {
     double yp[3] = {0, 0, 0}, X2[3] = {X[0], X[1], X[2]};
     if (pvar) {
       double V[6] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]}, Vi[6];
-      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / A.radius;
-      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / A.radius;
-      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / A.radius;
+      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / lm_radius;
+      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / lm_radius;
+      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / lm_radius;
       if (!spd3_inverse(V, Vi)) {
         bad += 1.0;
       } else {
@@ -948,8 +897,10 @@ __global__ void k_pt_scales(int64_t n3, const uint16_t* pt_kv, const double* dia
 __global__ __launch_bounds__(kThreads) void k_cam_update(int nc, const int32_t* cam_slot, const double* q,
                                                          const double* t, const double* cs, const double* yc,
                                                          const double* gc, double* q2, double* t2, double* scal,
-                                                         const double* intr, const int32_t* intr_idx, double* camtab2, int* chol_fail) {
+                                                         const double* intr, const int32_t* intr_idx, double* camtab2, int* chol_fail,
+                                                         const LmCtl* ctl) {
   __shared__ double s_red[3 * (kThreads / 64)];
+  if (lm_over(ctl)) return;
   double step = 0.0, xn = 0.0, gmax = 0.0;
   for (int i = threadIdx.x; i < nc; i += kThreads) {
     const int slot = cam_slot[i];
@@ -1032,6 +983,108 @@ __global__ void k_gmax_from_slots(const double* redsc, double* scal) {
 void launch_gmax_to_slot(double* redsc, int rank, hipStream_t s) { hipLaunchKernelGGL(k_gmax_to_slot, dim3(1), dim3(64), 0, s, redsc, rank); }
 void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t s) { hipLaunchKernelGGL(k_gmax_from_slots, dim3(1), dim3(64), 0, s, redsc, scal); }
 
+
+// ---- Levenberg-Marquardt control on the device ------------------------------------------------------------------
+// One thread takes the decisions of Ceres' TrustRegionMinimizer (trust_region_minimizer.cc, in its order) from the scalars
+// of the iteration that just ran: evaluation of the step, function / parameter / gradient tolerance, acceptance, the
+// radius rule of LevenbergMarquardtStrategy, the bookkeeping the summary reports.  The reference reaches this loop through
+// pyceres.solve (mpsfm/sfm/mapper/bundle_adjustment.py:285-293) with Ceres' default options.
+__device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* sc, const LmOpts& o);
+__global__ __launch_bounds__(64) void k_lm_decide(LmCtl* C, const double* sc, LmOpts o, LmCtl* host_copy) {
+  const bool live = C->term == kLmRunning;
+  if (live && threadIdx.x == 0) lm_decide_thread(C, sc, o);
+  __threadfence();
+  __syncthreads();
+  // the host's copy of the block goes straight into its pinned slot (device-visible host memory): no copy command in the loop
+  if (host_copy) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(C);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(host_copy);
+    for (int i = threadIdx.x; i < (int)(sizeof(LmCtl) / 4); i += 64) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+  }
+}
+__device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* sc, const LmOpts& o) {
+  auto trace = [&](double cost, double rad, int acc) {
+    if (C->trace_len < MPSFM_MAX_TRACE) {
+      C->trace_cost[C->trace_len] = cost; C->trace_radius[C->trace_len] = rad; C->trace_accepted[C->trace_len] = (uint8_t)acc; C->trace_len++;
+    }
+  };
+  auto next = [&]() {  // the tests at the top of the next iteration
+    if (C->term != kLmRunning) return;
+    if (C->iter >= o.max_iterations) C->term = MPSFM_TERM_MAX_ITERATIONS;
+    else if (C->radius <= o.min_radius) C->term = MPSFM_TERM_MIN_RADIUS;
+  };
+  C->accepted = 0;
+  C->iter += 1; C->n_jac_evals += 1; C->n_cost_evals += 1;
+  const int chol_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;
+  C->last_chol_fail = chol_fail;
+  const double x_cost = sc[U_X_COST];
+  const bool x_bad = sc[U_X_BAD] > 0.0;  // residual not evaluable or a landmark block not positive definite
+  C->last_x_cost = x_cost;
+  if (C->iter == 1) {
+    if (!isfinite(x_cost) || x_bad) { C->term = kLmNumericError; return; }
+    C->initial_cost = x_cost + C->fixed_cost;
+    C->cur_cost = x_cost;
+    trace(x_cost + C->fixed_cost, C->radius, 1);
+  }
+  if (C->check_gradient) {  // Ceres checks the gradient tolerance at iteration 0 and after each successful step
+    C->check_gradient = 0;
+    const double gmax = fmax(sc[U_GMAX_CAMS], sc[U_GMAX_PTS]);
+    if (gmax <= o.gradient_tolerance) { C->term = MPSFM_TERM_GRADIENT_TOLERANCE; C->iter -= 1; C->n_cost_evals -= 1; return; }
+  }
+  const double mcc = sc[U_MCC];
+  C->last_mcc = mcc;
+  const bool solver_ok = !x_bad && chol_fail == 0 && isfinite(mcc);
+  if (!(solver_ok && mcc > 0.0)) {
+    C->invalid_run += 1; C->n_unsuccess += 1;
+    if (C->invalid_run >= o.max_invalid_steps) C->term = MPSFM_TERM_INVALID_STEPS;
+    C->radius /= C->decrease_factor; C->decrease_factor *= 2.0;
+    trace(C->cur_cost + C->fixed_cost, C->radius, 0);
+    C->last_cand = DBL_MAX; C->last_rel = 0.0; C->last_step_norm = 0.0;
+    next();
+    return;
+  }
+  C->invalid_run = 0;
+  const double cand = (sc[U_BAD] > 0.0 || !isfinite(sc[U_CAND_COST])) ? DBL_MAX : sc[U_CAND_COST];
+  const double step_norm = sqrt(sc[U_STEP_SQ_PTS] + sc[U_STEP_SQ_CAMS]);
+  C->last_cand = cand; C->last_step_norm = step_norm;
+  if (step_norm <= o.parameter_tolerance * (C->x_norm + o.parameter_tolerance)) { C->term = MPSFM_TERM_PARAMETER_TOLERANCE; return; }
+  const double cost_change = x_cost - cand;
+  if (fabs(cost_change) <= o.function_tolerance * x_cost) { C->term = MPSFM_TERM_FUNCTION_TOLERANCE; return; }
+  const double rel = cost_change / mcc;
+  C->last_rel = rel;
+  if (rel > o.min_relative_decrease) {
+    C->accepted = 1;
+    C->x_norm = sqrt(sc[U_XN_SQ_PTS] + sc[U_XN_SQ_CAMS]);
+    C->cur_cost = cand;
+    const double u = 2.0 * rel - 1.0;
+    C->radius = fmin(o.max_radius, C->radius / fmax(1.0 / 3.0, 1.0 - u * u * u));
+    C->decrease_factor = 2.0;
+    C->n_success += 1;
+    C->check_gradient = 1;
+    trace(cand + C->fixed_cost, C->radius, 1);
+  } else {
+    C->radius /= C->decrease_factor; C->decrease_factor *= 2.0;
+    C->n_unsuccess += 1;
+    trace(C->cur_cost + C->fixed_cost, C->radius, 0);
+  }
+  next();
+}
+
+// the accepted candidate becomes the state (copies instead of the pointer swaps a host-side loop would do)
+__global__ __launch_bounds__(256) void k_lm_accept(const LmCtl* C, int nc, int64_t np, double* q, double* t, double* camtab, double* pts,
+                                                   const double* q2, const double* t2, const double* camtab2, const double* pts2) {
+  if (!C->accepted) return;  // also after the last iteration: the step that met a tolerance is not taken
+  const int64_t n_pts = 3 * np, n_q = 4 * (int64_t)nc, n_t = 3 * (int64_t)nc, n_tab = (int64_t)kCamRec * nc;
+  const int64_t total = n_pts + n_q + n_t + n_tab;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    if (i < n_pts) pts[i] = pts2[i];
+    else if (i < n_pts + n_q) q[i - n_pts] = q2[i - n_pts];
+    else if (i < n_pts + n_q + n_t) t[i - n_pts - n_q] = t2[i - n_pts - n_q];
+    else camtab[i - n_pts - n_q - n_t] = camtab2[i - n_pts - n_q - n_t];
+  }
+}
+
 // ---- launch wrappers ------------------------------------------------------------------------------
 void init_tile_tables(hipStream_t) {}
 
@@ -1073,9 +1126,27 @@ void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, in
 }
 void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs,
                        const double* yc, const double* gc, double* q2, double* t2, double* scal, hipStream_t s,
-                       const double* intr, const int32_t* intr_idx, double* camtab2, int* chol_fail) {
+                       const double* intr, const int32_t* intr_idx, double* camtab2, int* chol_fail, const LmCtl* ctl) {
   hipLaunchKernelGGL(k_cam_update, dim3(1), dim3(kThreads), 0, s, nc, cam_slot, q, t, cs, yc, gc, q2, t2, scal, intr, intr_idx,
-                     camtab2, chol_fail);
+                     camtab2, chol_fail, ctl);
+}
+void launch_lm_decide(LmCtl* ctl, const double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t s) {
+  hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(64), 0, s, ctl, scal, o, host_copy);
+}
+__global__ __launch_bounds__(256) void k_zero(double* p, int64_t n, const LmCtl* ctl) {
+  if (lm_over(ctl)) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.0;
+}
+void launch_zero(double* p, int64_t n, const LmCtl* ctl, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_zero, dim3((unsigned)std::min<int64_t>(2048, (n + 255) / 256)), dim3(256), 0, s, p, n, ctl);
+}
+void launch_lm_accept(const LmCtl* ctl, int nc, int64_t np, double* q, double* t, double* camtab, double* pts, const double* q2, const double* t2,
+                      const double* camtab2, const double* pts2, hipStream_t s) {
+  const int64_t total = 3 * np + (int64_t)nc * (4 + 3 + kCamRec);
+  static const int small = [] { const char* e = std::getenv("MPSFM_LM_DBG"); return e ? std::atoi(e) : 0; }();
+  const int grid = (small & 2) ? 1 : (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+  hipLaunchKernelGGL(k_lm_accept, dim3(grid), dim3(256), 0, s, ctl, nc, np, q, t, camtab, pts, q2, t2, camtab2, pts2);
 }
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t s) {
   hipLaunchKernelGGL(k_pts_sqnorm, dim3(nblocks), dim3(kThreads), 0, s, np, pt_kv, pts, part);

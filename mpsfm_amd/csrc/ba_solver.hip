@@ -38,12 +38,17 @@ void launch_cam_scales(int nc, const int32_t* cam_slot, const double* cmask, con
 void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, int jacobi, double* ps, hipStream_t);
 void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs, const double* yc,
                        const double* gc, double* q2, double* t2, double* scal, hipStream_t, const double* intr = nullptr,
-                       const int32_t* intr_idx = nullptr, double* camtab2 = nullptr, int* chol_fail = nullptr);
+                       const int32_t* intr_idx = nullptr, double* camtab2 = nullptr, int* chol_fail = nullptr, const LmCtl* ctl = nullptr);
+void launch_lm_decide(LmCtl* ctl, const double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t);
+void launch_zero(double* p, int64_t n, const LmCtl* ctl, hipStream_t);
+void launch_lm_accept(const LmCtl* ctl, int nc, int64_t np, double* q, double* t, double* camtab, double* pts, const double* q2, const double* t2,
+                      const double* camtab2, const double* pts2, hipStream_t);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_gmax_to_slot(double* redsc, int rank, hipStream_t);
 void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const LevelPlanDev* lp);
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t, DenseOverlap* ov, const LevelPlanDev* lp,
+                        const LmCtl* ctl = nullptr);
 bool dense_level(const DenseOverlap* ov, const LevelPlanDev* lp);
 int dense_plain_max_tiles();
 int dense_inv_rows();
@@ -143,7 +148,7 @@ struct HandleResources {
   std::vector<hipStream_t> streams[16];
   std::vector<hipEvent_t> timing_events[16], plain_events[16];
   std::vector<void*> pinned[16];  // blocks of kPinnedBytes
-  static constexpr size_t kPinnedBytes = 512;
+  static constexpr size_t kPinnedBytes = 4096;
   static int dev() { int d = 0; (void)hipGetDevice(&d); return std::min(std::max(d, 0), 15); }
 };
 HandleResources& pool() { static HandleResources* r = new HandleResources(); return *r; }
@@ -400,6 +405,9 @@ struct mpsfm_ba_handle {
   double *d_Sblk = nullptr, *d_gc = nullptr, *d_wv = nullptr, *d_diagU = nullptr, *d_redsc = nullptr;
   double *d_part = nullptr, *d_part2 = nullptr, *d_scal = nullptr, *d_costpart = nullptr;
   double* h_scal = nullptr;  // pinned
+  LmCtl* d_ctl = nullptr;    // Levenberg-Marquardt control block (device) and the two pinned slots its copies land in
+  LmCtl* h_ctl = nullptr;
+  hipEvent_t ev2[4] = {nullptr, nullptr, nullptr, nullptr};  // second set of phase events (two iterations are in flight)
   double *d_A = nullptr, *d_yc = nullptr, *d_dwork = nullptr;
   int* d_fail = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -427,6 +435,9 @@ static void free_handle(mpsfm_ba_handle* h) {
   for (void* p : ptrs) cached_free(p);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
   release_pinned(h->h_scal);
+  release_pinned(h->h_ctl);
+  cached_free(h->d_ctl);
+  for (auto& e : h->ev2) release_event(e, true);
   for (auto& e : h->ev) release_event(e, true);
   for (auto& e : h->ov.evF) release_event(e, false);
   for (auto& e : h->ov.evB) release_event(e, false);
@@ -1226,12 +1237,16 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_costpart, (size_t)1024 * 4))) return rc;
   static_assert(sizeof(double) * U_COUNT * 2 <= HandleResources::kPinnedBytes, "pinned scalar block too small");
   HIP_TRY(pooled_pinned((void**)&h->h_scal));
+  static_assert(sizeof(LmCtl) * 2 <= HandleResources::kPinnedBytes, "pinned block too small for two control-block copies");
+  HIP_TRY(pooled_pinned((void**)&h->h_ctl));
+  if ((rc = dev_alloc(&h->d_ctl, 1))) return rc;
+  for (auto& e : h->ev2) HIP_TRY(pooled_event(&e, true));
   const size_t ntiles = (size_t)(h->nt + 1) * (h->nt + 2) / 2;
   if ((rc = dev_alloc(&h->d_A, ntiles * 1024))) return rc;
   if ((rc = dev_alloc(&h->d_dwork, dense_work_doubles(h->nt)))) return rc;
   if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
   if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
-  HIP_TRY(hipMemset(h->d_fail, 0, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(h->d_fail, 0, sizeof(int), h->stream));
   for (auto& e : h->ev) HIP_TRY(pooled_event(&e, true));
   // tuning / test overrides of the dense factorisation, read once per handle
   if (const char* e = std::getenv("MPSFM_CHOL_NB")) h->ov.nb = std::max(0, std::atoi(e));
@@ -1247,8 +1262,9 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     for (auto& e : h->ov.evF) HIP_TRY(pooled_event(&e, false));
     for (auto& e : h->ov.evB) HIP_TRY(pooled_event(&e, false));
   }
-  HIP_TRY(hipMemset(h->d_ps, 0, nps * 3 * sizeof(double)));
-  HIP_TRY(hipMemset(h->d_yc, 0, (size_t)std::max(h->n, 1) * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(h->d_ps, 0, nps * 3 * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_yc, 0, (size_t)std::max(h->n, 1) * sizeof(double), h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   init_tile_tables(h->stream);
   (void)st;
   lap("allocate work buffers");
@@ -1293,8 +1309,9 @@ static int upload_state(mpsfm_ba_handle* h, const mpsfm_ba_state* st, bool as_in
   return 0;
 }
 
-static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius) {
+static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullptr) {
   SweepArgs a{};
+  a.ctl = ctl;
   a.chunks = h->d_chunks; a.chunk_cams = h->d_chunk_cams; a.rec_cam = h->d_rec_cam; a.rec_meta = h->d_rec_meta;
   a.rec_xy = h->d_rec_xy; a.rec_d = h->d_rec_d; a.rec_m = h->d_rec_m; a.rec_a = h->d_rec_a;
   a.pt_rec_start = h->d_pt_rec_start; a.pt_kv = h->d_pt_kv; a.blk_desc = h->d_blk_desc; a.blk_ent_start = h->d_blk_ent_start; a.ents = h->d_ents;
@@ -1344,10 +1361,10 @@ static int prepare_scales(mpsfm_ba_handle* h) {
 }
 
 // one track sweep at the current state: fills the reduced buffer and its scalar tail
-static int run_track_sweep(mpsfm_ba_handle* h, double radius) {
+static int run_track_sweep(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullptr) {
   hipStream_t s = h->stream;
-  HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double) * (size_t)h->red_count, s));
-  SweepArgs a = sweep_args(h, radius);
+  launch_zero(h->d_red, h->red_count, ctl, s);
+  SweepArgs a = sweep_args(h, radius, ctl);
   launch_track_sweep(a, h->nchunks, false, s);
   if (h->nchunks + h->nlong > 0)
     launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, sharded(h) ? nullptr : h->d_scal + U_X_COST);
@@ -1356,7 +1373,7 @@ static int run_track_sweep(mpsfm_ba_handle* h, double radius) {
   return 0;
 }
 
-static int run_dense(mpsfm_ba_handle* h, double radius) {
+static int run_dense(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullptr) {
   hipStream_t s = h->stream;
   // d_fail is zero here: cleared at creation and re-armed by k_cam_update after every read
   if (h->n > 0) {
@@ -1365,9 +1382,9 @@ static int run_dense(mpsfm_ba_handle* h, double radius) {
     double* pinv = dense_pinv(h->d_dwork, h->nt, &h->ov, &h->lp);
     const bool listed = level && !pinv;
     AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius,
-                    h->opt.min_lm_diagonal, h->opt.max_lm_diagonal, h->d_A, pinv, listed ? h->lp.d_asm_tiles : nullptr, listed ? h->lp.n_asm : 0};
+                    h->opt.min_lm_diagonal, h->opt.max_lm_diagonal, h->d_A, pinv, listed ? h->lp.d_asm_tiles : nullptr, listed ? h->lp.n_asm : 0, ctl};
     launch_assemble(as, s);
-    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->lp);
+    launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->lp, ctl);
   }
   return 0;
 }
@@ -1429,120 +1446,92 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     x_norm = std::sqrt(v + h->h_scal[U_XN_SQ_CAMS]);
   }
 
-  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
-  double x_cost = 0.0, cur_cost = 0.0;
-  int iter = 0, invalid_run = 0, term = -1;
-  bool check_gradient = true;  // Ceres checks the gradient tolerance at iteration 0 and after each successful step
-  float ms;
-  auto trace = [&](double cost, double rad, int acc) {
-    if (sum->trace_len < MPSFM_MAX_TRACE) {
-      sum->trace_cost[sum->trace_len] = cost; sum->trace_radius[sum->trace_len] = rad;
-      sum->trace_accepted[sum->trace_len] = (uint8_t)acc; sum->trace_len++;
-    }
-  };
-
-  while (term < 0) {
-    if (iter >= o.max_num_iterations) { term = MPSFM_TERM_MAX_ITERATIONS; break; }
-    if (radius <= o.min_trust_region_radius) { term = MPSFM_TERM_MIN_RADIUS; break; }
-    ++iter;
-    // ---- device work of one LM iteration ---------------------------------------------------
-    HIP_TRY(hipEventRecord(h->ev[0], s));
-    if (int rc = run_track_sweep(h, radius)) return rc;
+  // ---- Levenberg-Marquardt loop.  The decisions are taken on the device (k_lm_decide, LmCtl in common.h): the host
+  // enqueues iteration i+1 BEFORE it looks at the outcome of iteration i, so the stream never runs dry, and only reads a
+  // pinned copy of the control block one iteration late.  When that copy says the solve is over, the one iteration queued
+  // ahead returns at once in every kernel.  Every rank of a sharded run sees the same decisions at the same iteration, so
+  // all of them enqueue the same sequence of collectives.
+  {
+    LmCtl c0;
+    std::memset(&c0, 0, sizeof(c0));
+    c0.radius = o.initial_trust_region_radius; c0.decrease_factor = 2.0; c0.x_norm = x_norm; c0.fixed_cost = fixed;
+    c0.term = kLmRunning; c0.check_gradient = 1;
+    if (o.max_num_iterations <= 0) c0.term = MPSFM_TERM_MAX_ITERATIONS;
+    else if (c0.radius <= o.min_trust_region_radius) c0.term = MPSFM_TERM_MIN_RADIUS;
+    h->h_ctl[0] = c0;
+    HIP_TRY(hipMemcpyAsync(h->d_ctl, &h->h_ctl[0], sizeof(LmCtl), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // the pinned slot is reused below
+  }
+  const LmOpts lo{o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.min_relative_decrease, o.max_trust_region_radius,
+                  o.min_trust_region_radius, o.max_num_iterations, o.max_num_consecutive_invalid_steps};
+  static const int lm_dbg = [] { const char* e = std::getenv("MPSFM_LM_DBG"); return e ? std::atoi(e) : 0; }();
+  const LmCtl* ctl = (lm_dbg & 1) ? nullptr : h->d_ctl;
+  double host_radius = o.initial_trust_region_radius;
+  auto enqueue_iteration = [&](int it) -> int {
+    hipEvent_t* ev = (it & 1) ? h->ev2 : h->ev;
+    HIP_TRY(hipEventRecord(ev[0], s));
+    if (int rc = run_track_sweep(h, host_radius, ctl)) return rc;
     if (int rc = allreduce_dev(h, h->d_red, h->red_count)) return rc;
-    HIP_TRY(hipEventRecord(h->ev[1], s));
-    if (int rc = run_dense(h, radius)) return rc;
-    HIP_TRY(hipEventRecord(h->ev[2], s));
+    HIP_TRY(hipEventRecord(ev[1], s));
+    if (int rc = run_dense(h, host_radius, ctl)) return rc;
+    HIP_TRY(hipEventRecord(ev[2], s));
     launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s,
-                      h->d_intr, h->d_intr_idx, h->d_camtab2, h->d_fail);
+                      h->d_intr, h->d_intr_idx, h->d_camtab2, h->d_fail, ctl);
     {
-      SweepArgs a = sweep_args(h, radius);
+      SweepArgs a = sweep_args(h, host_radius, ctl);
       launch_update_sweep(a, h->nchunks, s);
       if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part2, h->nchunks + h->nlong, 8, 5, 0u, h->d_scal, s);
     }
     if (int rc = allreduce_dev(h, h->d_scal, 5)) return rc;
     if (sharded(h))  // the all-reduced scalars of the track sweep (single rank: written by its reduction directly): cost and
       launch_gmax_from_slots(h->d_redsc, h->d_scal, s);  // bad count summed, landmark-gradient maximum over the rank slots
-    HIP_TRY(hipEventRecord(h->ev[3], s));
-    HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * U_COUNT, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); sum->time_linearize_s += 1e-3 * ms;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[1], h->ev[2])); sum->time_dense_s += 1e-3 * ms;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); sum->time_update_s += 1e-3 * ms;
-    ++n_jac_evals; ++n_cost_evals;
-    const double* sc = h->h_scal;
-    const int h_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;  // set by the factorisation, published by k_cam_update
-
-    // ---- decisions (Ceres trust_region_minimizer.cc order) ------------------------------------
-    x_cost = sc[U_X_COST];
-    const bool x_bad = sc[U_X_BAD] > 0.0;  // residual not evaluable or a landmark block not PD
-    if (iter == 1) {
-      if (!std::isfinite(x_cost) || x_bad)
-        return finish(fail(MPSFM_ENUMERIC, "the initial point cannot be evaluated (non-finite residual or depth <= 0 in a log-depth block)"));
-      sum->initial_cost = x_cost + fixed;
-      cur_cost = x_cost;
-      trace(x_cost + fixed, radius, 1);
-    }
-    if (check_gradient) {
-      check_gradient = false;
-      const double gmax = std::max(sc[U_GMAX_CAMS], sc[U_GMAX_PTS]);
-      if (gmax <= o.gradient_tolerance) { term = MPSFM_TERM_GRADIENT_TOLERANCE; --iter; --n_cost_evals; break; }
-    }
-    const double mcc = sc[U_MCC];
-    const bool solver_ok = !x_bad && h_fail == 0 && std::isfinite(mcc);
-    if (!(solver_ok && mcc > 0.0)) {
-      ++invalid_run;
-      sum->num_unsuccessful_steps++;
-      if (invalid_run >= o.max_num_consecutive_invalid_steps) term = MPSFM_TERM_INVALID_STEPS;
-      radius /= decrease_factor; decrease_factor *= 2.0;
-      trace(cur_cost + fixed, radius, 0);
+    launch_lm_decide(h->d_ctl, h->d_scal, lo, &h->h_ctl[it & 1], s);
+    launch_lm_accept(h->d_ctl, h->nc, h->np, h->d_q, h->d_t, h->d_camtab, h->d_pts, h->d_q2, h->d_t2, h->d_camtab2, h->d_pts2, s);
+    HIP_TRY(hipEventRecord(ev[3], s));
+    return 0;
+  };
+  LmCtl last = h->h_ctl[0];
+  if (last.term == kLmRunning) {
+    if (int rc = enqueue_iteration(1)) return rc;
+    static const bool speculate = [] { const char* e = std::getenv("MPSFM_LM_SPECULATE"); return !(e && std::atoi(e) == 0); }();
+    for (int it = 1;; ++it) {
+      if (speculate) { if (int rc = enqueue_iteration(it + 1)) return rc; }  // ahead of the news about iteration `it`
+      hipEvent_t* ev = (it & 1) ? h->ev2 : h->ev;
+      HIP_TRY(hipEventSynchronize(ev[3]));
+      HIP_TRY(hipGetLastError());
+      float ms;
+      HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); sum->time_linearize_s += 1e-3 * ms;
+      HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); sum->time_dense_s += 1e-3 * ms;
+      HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); sum->time_update_s += 1e-3 * ms;
+      const LmCtl prev = last;
+      last = h->h_ctl[it & 1];
       if (o.verbose > 0) {
-        std::fprintf(stderr, "[mpsfm_ba] it %3d invalid step (chol_fail=%d mcc=%.3e) radius %.3e\n", iter, h_fail, mcc, radius);
-        // diagnostics: which intermediate holds the non-finite value
-        std::vector<double> yc((size_t)std::max(h->n, 1)), red((size_t)h->red_count);
-        (void)hipMemcpy(yc.data(), h->d_yc, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(red.data(), h->d_red, sizeof(double) * (size_t)h->red_count, hipMemcpyDeviceToHost);
-        int64_t bad_y = 0, bad_S = 0, bad_rest = 0;
-        for (int i = 0; i < h->n; ++i) bad_y += !std::isfinite(yc[(size_t)i]);
-        for (int64_t i = 0; i < h->sblk_count; ++i) bad_S += !std::isfinite(red[(size_t)i]);
-        for (int64_t i = h->sblk_count; i < h->red_count; ++i) bad_rest += !std::isfinite(red[(size_t)i]);
-        std::fprintf(stderr, "[mpsfm_ba]     non-finite: y_c %lld of %d, S %lld, g/w/diagU/scalars %lld; scalars:", (long long)bad_y, h->n,
-                     (long long)bad_S, (long long)bad_rest);
-        for (int i = 0; i < U_COUNT; ++i) std::fprintf(stderr, " %.3e", sc[i]);
-        std::fprintf(stderr, "\n");
+        if (last.last_mcc > 0.0 && last.last_cand != DBL_MAX)
+          std::fprintf(stderr, "[mpsfm_ba] it %3d cost %.9e cand %.9e rel %.3e radius %.3e |step| %.3e\n", it, last.last_x_cost + fixed,
+                       last.last_cand + fixed, last.last_rel, last.radius, last.last_step_norm);
+        else
+          std::fprintf(stderr, "[mpsfm_ba] it %3d invalid step (chol_fail=%d mcc=%.3e) radius %.3e\n", it, last.last_chol_fail, last.last_mcc, last.radius);
       }
-      continue;
+      (void)prev;
+      host_radius = last.radius;
+      if (last.term != kLmRunning) break;
+      if (!speculate) { if (int rc = enqueue_iteration(it + 1)) return rc; }
     }
-    invalid_run = 0;
-    const double cand = (sc[U_BAD] > 0.0 || !std::isfinite(sc[U_CAND_COST])) ? DBL_MAX : sc[U_CAND_COST];
-    const double step_norm = std::sqrt(sc[U_STEP_SQ_PTS] + sc[U_STEP_SQ_CAMS]);
-    if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { term = MPSFM_TERM_PARAMETER_TOLERANCE; break; }
-    const double cost_change = x_cost - cand;
-    if (std::fabs(cost_change) <= o.function_tolerance * x_cost) { term = MPSFM_TERM_FUNCTION_TOLERANCE; break; }
-    const double rel = cost_change / mcc;
-    if (rel > o.min_relative_decrease) {
-      std::swap(h->d_q, h->d_q2); std::swap(h->d_t, h->d_t2); std::swap(h->d_pts, h->d_pts2); std::swap(h->d_camtab, h->d_camtab2);
-      x_norm = std::sqrt(sc[U_XN_SQ_PTS] + sc[U_XN_SQ_CAMS]);
-      cur_cost = cand;
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3.0));
-      radius = std::min(o.max_trust_region_radius, radius);
-      decrease_factor = 2.0;
-      sum->num_successful_steps++;
-      check_gradient = true;
-      trace(cand + fixed, radius, 1);
-    } else {
-      radius /= decrease_factor; decrease_factor *= 2.0;
-      sum->num_unsuccessful_steps++;
-      trace(cur_cost + fixed, radius, 0);
-    }
-    if (o.verbose > 0)
-      std::fprintf(stderr, "[mpsfm_ba] it %3d cost %.9e cand %.9e rel %.3e radius %.3e |step| %.3e\n", iter, x_cost + fixed,
-                   cand + fixed, rel, radius, step_norm);
+    HIP_TRY(hipStreamSynchronize(s));  // the iteration queued ahead has drained (every kernel of it returned at once)
   }
-  sum->final_cost = cur_cost + fixed;
-  sum->num_iterations = iter;
-  sum->termination = term;
-  sum->final_radius = radius;
+  h->last_radius = last.radius;
+  n_cost_evals = last.n_cost_evals; n_jac_evals = last.n_jac_evals;
+  if (last.term == kLmNumericError)
+    return finish(fail(MPSFM_ENUMERIC, "the initial point cannot be evaluated (non-finite residual or depth <= 0 in a log-depth block)"));
+  sum->initial_cost = last.initial_cost;
+  sum->final_cost = last.cur_cost + fixed;
+  sum->num_iterations = last.iter;
+  sum->num_successful_steps = last.n_success;
+  sum->num_unsuccessful_steps = last.n_unsuccess;
+  sum->termination = last.term;
+  sum->final_radius = last.radius;
+  sum->trace_len = last.trace_len;
+  for (int i = 0; i < last.trace_len; ++i) { sum->trace_cost[i] = last.trace_cost[i]; sum->trace_radius[i] = last.trace_radius[i]; sum->trace_accepted[i] = last.trace_accepted[i]; }
   return finish(0);
 }
 
@@ -1680,13 +1669,14 @@ int mpsfm_ba_solve_resident(mpsfm_ba_handle* h, mpsfm_ba_summary* summary) {
 int mpsfm_ba_get_state(mpsfm_ba_handle* h, mpsfm_ba_state* st) {
   if (!h || !st) return fail(MPSFM_EINVAL, "handle or state is NULL");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));  // then blocking copies: pageable destinations (see upload_state)
+  HIP_TRY(hipStreamSynchronize(h->stream));  // copies on the handle's own stream, never the legacy null stream (see solve_impl)
   if (h->nc > 0) {
-    HIP_TRY(hipMemcpy(st->cam_quat_xyzw, h->d_q, sizeof(double) * 4 * h->nc, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(st->cam_t, h->d_t, sizeof(double) * 3 * h->nc, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(st->cam_quat_xyzw, h->d_q, sizeof(double) * 4 * h->nc, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(st->cam_t, h->d_t, sizeof(double) * 3 * h->nc, hipMemcpyDeviceToHost, h->stream));
   }
   std::vector<double> sorted((size_t)h->np * 3);
-  if (h->np > 0) HIP_TRY(hipMemcpy(sorted.data(), h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToHost));
+  if (h->np > 0) HIP_TRY(hipMemcpyAsync(sorted.data(), h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   for (int64_t k = 0; k < h->np; ++k) {
     double* d = st->pts + 3 * (size_t)h->perm[k];
     d[0] = sorted[3 * k]; d[1] = sorted[3 * k + 1]; d[2] = sorted[3 * k + 2];
@@ -1786,7 +1776,8 @@ int mpsfm_ba_get_reduced_system(mpsfm_ba_handle* h, double* S, double* rhs, int3
   if (n != h->n_user) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
   HIP_TRY(hipSetDevice(h->device));
   std::vector<double> red((size_t)h->red_count);
-  HIP_TRY(hipMemcpy(red.data(), h->d_red, sizeof(double) * red.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(red.data(), h->d_red, sizeof(double) * red.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   const double* Sb = red.data(); const double* gc = Sb + h->sblk_count; const double* wv = gc + h->n; const double* dU = wv + h->n;
   const mpsfm_ba_options& o = h->opt;
   const BlockSky sky{h->sky_first.data(), h->sky_start.data(), h->sky_index.empty() ? nullptr : h->sky_index.data(), h->ncv};
@@ -1811,7 +1802,8 @@ int mpsfm_ba_get_dense_solution(mpsfm_ba_handle* h, double* y, int32_t n) {
   if (n != h->n_user) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
   HIP_TRY(hipSetDevice(h->device));
   std::vector<double> ys((size_t)std::max(h->n, 1));
-  HIP_TRY(hipMemcpy(ys.data(), h->d_yc, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(ys.data(), h->d_yc, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   for (int i = 0; i < n; ++i) y[i] = ys[(size_t)(6 * h->nat_slot[(size_t)(i / 6)] + i % 6)];
   return 0;
 }

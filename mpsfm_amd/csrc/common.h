@@ -86,6 +86,27 @@ enum {
   U_GMAX_PTS = 10, U_CHOL_FAIL = 11, U_COUNT = 16
 };
 
+// Levenberg-Marquardt control block on the device.  The accept / reject decision of an iteration (Ceres
+// trust_region_minimizer.cc) is taken by a one-thread kernel (k_lm_decide) from the scalars the sweeps leave behind, so the
+// host enqueues iteration i+1 while iteration i still runs and only reads a copy of this block one iteration late: no
+// stream synchronisation inside the loop.  Every kernel of an iteration returns at once when `term` says the solve is
+// over (the one iteration enqueued ahead of the news).
+struct LmCtl {
+  double radius, decrease_factor, x_norm, cur_cost, fixed_cost, initial_cost;
+  double last_x_cost, last_cand, last_rel, last_step_norm, last_mcc;  // diagnostics of the last decided iteration
+  int32_t term;          // kLmRunning, MPSFM_TERM_* once decided, kLmNumericError: the initial point cannot be evaluated
+  int32_t iter, invalid_run, check_gradient, accepted, n_success, n_unsuccess, n_cost_evals, n_jac_evals, last_chol_fail, trace_len, pad_;
+  double trace_cost[MPSFM_MAX_TRACE], trace_radius[MPSFM_MAX_TRACE];
+  uint8_t trace_accepted[MPSFM_MAX_TRACE];
+};
+constexpr int32_t kLmRunning = -1, kLmNumericError = -2;
+struct LmOpts {
+  double function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease, max_radius, min_radius;
+  int32_t max_iterations, max_invalid_steps;
+};
+__device__ inline bool lm_over(const LmCtl* c) { return c != nullptr && __hip_atomic_load(&c->term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kLmRunning; }
+__device__ inline double lm_radius_of(const LmCtl* c) { return __hip_atomic_load(&c->radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---- small device math -------------------------------------------------------------------
 __host__ __device__ inline void loss_eval(int type, double a, double s, double& rho0, double& rho1) {
   if (type == MPSFM_LOSS_SOFT_L1) {
@@ -252,6 +273,7 @@ struct SweepArgs {
   const double* camtab2;   // candidate cameras
   double* pts2;            // candidate landmarks
   double* part2;           // [nchunks][8]
+  const LmCtl* ctl;        // inside a solve: trust-region radius and the stop flag live on the device (NULL: `radius` above)
 };
 
 struct CostArgs {
@@ -307,6 +329,7 @@ struct AssembleArgs {
   double* Pinv;  // accumulators of the inverse propagation (same tile indexing as A), zeroed here; may be NULL
   const int32_t* tile_list;  // packed ids of the tiles to assemble (one workgroup each), NULL: all (nt+1)(nt+2)/2
   int32_t n_list;
+  const LmCtl* ctl;  // as in SweepArgs
 };
 
 

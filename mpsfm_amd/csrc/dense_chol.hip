@@ -18,6 +18,8 @@ constexpr int kPlainMaxTiles = 64;  // up to this many tile columns: one outer p
 
 // one workgroup per lower tile (including the rhs tile row)
 __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
+  if (lm_over(P.ctl)) return;
+  const double lm_radius = P.ctl ? lm_radius_of(P.ctl) : P.radius;
   // decode tile id -> (ti, tj), ti >= tj, ti in [0, nt], tj in [0, nt-1]
   const int64_t id = P.tile_list ? (int64_t)P.tile_list[blockIdx.x] : (int64_t)blockIdx.x;
   int ti = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
         else if (br < bc) v = P.Sblk[sky_block(P.sky, br, bc) * 36 + a * 6 + b];
         else if (br > bc) v = P.Sblk[sky_block(P.sky, bc, br) * 36 + b * 6 + a];
         else v = P.Sblk[sky_block(P.sky, br, br) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
-        if (R == C) v += fmin(fmax(P.diagU[R], P.min_diag), P.max_diag) / P.radius;
+        if (R == C) v += fmin(fmax(P.diagU[R], P.min_diag), P.max_diag) / lm_radius;
       }
     }
     T[e] = v;
@@ -509,9 +511,11 @@ struct LevelArgs {
   double* A; double* LinvT; double* Pinv;
   const CholItem* items; const int32_t* srcs; const int32_t* rows;
   int* fail; int32_t nt, dbg;
+  const LmCtl* ctl;
 };
 
 __global__ __launch_bounds__(kStepThreads) void k_chol_level(LevelArgs G) {
+  if (lm_over(G.ctl)) return;
   __shared__ double s_T[kTile][kTile + 1];
   __shared__ double s_X[kTile][kTile + 1];
   __shared__ __attribute__((aligned(16))) double s_Lt[kTile * kTile];
@@ -601,9 +605,10 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_level(LevelArgs G) {
 // per tile column j of the level: v = z_j - sum_{i in struct(j)} L(i,j)^T y_i (all those i are ancestors: final), then
 // y_j = L(j,j)^-T v with the stored inverse.  z_j is row 0 of the right-hand-side tile (nt, j).
 __global__ __launch_bounds__(256) void k_back_level(const double* A, const double* LinvT, const int32_t* cols, const int32_t* struct_start,
-                                                    const int32_t* struct_rows, int nt, int n, double* ybuf, double* y) {
+                                                    const int32_t* struct_rows, int nt, int n, double* ybuf, double* y, const LmCtl* ctl) {
   __shared__ double s_part[8][kTile];
   __shared__ double s_v[kTile];
+  if (lm_over(ctl)) return;
   const int j = cols[blockIdx.x];
   const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int r0 = struct_start[j], r1 = struct_start[j + 1] - 1;  // the last entry is the right-hand-side row
@@ -735,7 +740,8 @@ __global__ __launch_bounds__(256) void k_backsub_group(const double* A, const do
 
 // ---- y = L^-T z from the inverse accumulators (two launches) --------------------------------------------
 // w_i = L(i,i)^-T z_i, z_i = row 0 of the right-hand-side tile (nt, i); y starts as w
-__global__ __launch_bounds__(64) void k_inv_w(const double* A, const double* LinvT, int nt, int n, double* wbuf, double* y) {
+__global__ __launch_bounds__(64) void k_inv_w(const double* A, const double* LinvT, int nt, int n, double* wbuf, double* y, const LmCtl* ctl) {
+  if (lm_over(ctl)) return;
   const int i = blockIdx.x, r = threadIdx.x & 31, h = threadIdx.x >> 5;
   const double* z = A + lt_tile(nt, i) * kTileElems;
   const double* Li = LinvT + (size_t)i * kTileElems + r * kTile;
@@ -750,8 +756,9 @@ __global__ __launch_bounds__(64) void k_inv_w(const double* A, const double* Lin
 }
 // y_k -= sum_{i>k, i = k+1+s (mod kInvSplit)} P(i,k)^T w_i : the long columns are cut into kInvSplit workgroups
 constexpr int kInvSplit = 4;
-__global__ __launch_bounds__(256) void k_inv_y(const double* Pinv, const double* wbuf, int nt, int n, double* y) {
+__global__ __launch_bounds__(256) void k_inv_y(const double* Pinv, const double* wbuf, int nt, int n, double* y, const LmCtl* ctl) {
   __shared__ double s_part[8][kTile];
+  if (lm_over(ctl)) return;
   const int k = blockIdx.x, c = threadIdx.x & 31, part = threadIdx.x >> 5;
   if (k + 1 + (int)blockIdx.y >= nt) return;
   double sacc = 0.0;
@@ -809,14 +816,15 @@ double* dense_pinv(double* work, int nt, const DenseOverlap* ov, const LevelPlan
 // ov (may be NULL): a second stream and events.  With it the update of an outer panel is split: the tile
 // columns of the NEXT panel are updated on the main stream (the factorisation needs them next), the columns
 // beyond run on the second stream under the next panel's factorisation steps.
-void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov, const LevelPlanDev* lp) {
+void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* fail, hipStream_t s, DenseOverlap* ov, const LevelPlanDev* lp,
+                        const LmCtl* ctl) {
   if (nt <= 0) return;
   double* LinvT = work;
   double* zbuf = work + (size_t)nt * kTileElems;
   double* wbuf = zbuf + (size_t)nt * kTile;
   if (dense_level(ov, lp)) {
     double* Pinv = dense_pinv(work, nt, ov, lp);
-    LevelArgs G{A, LinvT, Pinv, nullptr, lp->d_srcs, lp->d_rows, fail, nt, g_dbg_flags};
+    LevelArgs G{A, LinvT, Pinv, nullptr, lp->d_srcs, lp->d_rows, fail, nt, g_dbg_flags, ctl};
     for (int l = 0; l < lp->nlevels; ++l) {
       const int grid = lp->h_launch_start[l + 1] - lp->h_launch_start[l];
       if (grid <= 0) continue;
@@ -824,15 +832,15 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
       hipLaunchKernelGGL(k_chol_level, dim3((unsigned)grid), dim3(kStepThreads), 0, s, G);
     }
     if (Pinv) {
-      hipLaunchKernelGGL(k_inv_w, dim3(nt), dim3(64), 0, s, A, LinvT, nt, n, wbuf, y);
-      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, Pinv, wbuf, nt, n, y);
+      hipLaunchKernelGGL(k_inv_w, dim3(nt), dim3(64), 0, s, A, LinvT, nt, n, wbuf, y, ctl);
+      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, Pinv, wbuf, nt, n, y, ctl);
       return;
     }
     for (int l = 0; l < lp->nlevels; ++l) {
       const int grid = lp->h_back_start[l + 1] - lp->h_back_start[l];
       if (grid <= 0) continue;
       hipLaunchKernelGGL(k_back_level, dim3((unsigned)grid), dim3(256), 0, s, A, LinvT, lp->d_back_cols + lp->h_back_start[l], lp->d_struct_start,
-                         lp->d_struct_rows, nt, n, zbuf, y);
+                         lp->d_struct_rows, nt, n, zbuf, y, ctl);
     }
     return;
   }

@@ -139,14 +139,17 @@ extern "C" int mpsfm_depth_blocks(const mpsfm_depth_gather* g, int32_t device, u
   if (device < 0 || device >= ndev) return pfail(MPSFM_EINVAL, "device ordinal out of range");
   if (device >= kMaxDevices) return pfail(MPSFM_EUNSUPPORTED, "device ordinals beyond 15 are not supported (per-device pools)");
   PRI_TRY(hipSetDevice(device));
-  struct Blocks {
+  struct Blocks {  // a pooled non-blocking stream per call, never the legacy null stream (see DevBuf in tri_kernels.hip)
     std::vector<void*> v;
+    hipStream_t st = nullptr;
     ~Blocks() {
-      if (!v.empty()) (void)hipStreamSynchronize(nullptr);
+      if (st) (void)hipStreamSynchronize(st);
       for (void* p : v) cached_free(p);
+      release_stream(st);
     }
     void* get(size_t bytes) { void* p = cached_malloc(bytes ? bytes : 1); if (p) v.push_back(p); return p; }
   } B;
+  PRI_TRY(pooled_stream(&B.st));
   const size_t ni = (size_t)g->n_images, no = (size_t)g->n_obs, npix = (size_t)off[ni];
   GatherArgs A{};
   A.n_obs = g->n_obs;
@@ -178,10 +181,11 @@ extern "C" int mpsfm_depth_blocks(const mpsfm_depth_gather* g, int32_t device, u
   if (!A.flags) return pfail(MPSFM_ENOMEM, "hipMalloc failed");
   A.d_out = outs[0]; A.z_out = outs[1]; A.mag = outs[2]; A.par = outs[3]; A.whi = outs[4];
   if (int rc = staged_drain()) return rc;
-  hipLaunchKernelGGL(k_depth_blocks, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, 0, A);
+  hipLaunchKernelGGL(k_depth_blocks, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, B.st, A);
   PRI_TRY(hipGetLastError());
-  PRI_TRY(hipMemcpy(flags, A.flags, no, hipMemcpyDeviceToHost));
+  PRI_TRY(hipMemcpyAsync(flags, A.flags, no, hipMemcpyDeviceToHost, B.st));
   double* hosts[5] = {depth, depth3d, magnitude, param, whitened};
-  for (int k = 0; k < 5; ++k) PRI_TRY(hipMemcpy(hosts[k], outs[k], sizeof(double) * no, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 5; ++k) PRI_TRY(hipMemcpyAsync(hosts[k], outs[k], sizeof(double) * no, hipMemcpyDeviceToHost, B.st));
+  PRI_TRY(hipStreamSynchronize(B.st));
   return 0;
 }

@@ -25,11 +25,23 @@ static int tfail(int code, const std::string& m) { g_err = m; return code; }
 
 struct DevBuf {
   std::vector<void*> ptrs;
-  // the kernels of this file run on the null stream: it must be idle before the blocks go back to the caching
-  // allocator (an early return on a failed call would otherwise free memory that is still in use)
+  // Every call works on a non-blocking stream of its own from the pool, never on the legacy null stream: the library is
+  // called from several host threads (tests, threaded callers), and null-stream copies / fills issued by one thread while
+  // another thread's solve had a deep queue of launches in flight corrupted that solve (MI355X, ROCm 7.2: reproduced with
+  // tests/test_gpu_fuzz.py::test_random_problems_concurrently until the last null-stream call was gone).
+  hipStream_t st = nullptr;
+  DevBuf() { if (pooled_stream(&st) != hipSuccess) st = nullptr; }
+  // the stream must be idle before the blocks go back to the caching allocator (an early return on a failed call would
+  // otherwise free memory that is still in use) and before the stream goes back to the pool
   ~DevBuf() {
-    if (!ptrs.empty()) (void)hipStreamSynchronize(nullptr);
+    if (st) (void)hipStreamSynchronize(st);
     for (void* p : ptrs) cached_free(p);
+    release_stream(st);
+  }
+  // device -> caller memory, complete on return
+  hipError_t down(void* host, const void* dev, size_t bytes) {
+    hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
   }
   template <typename T>
   T* up(const T* host, size_t n, bool copy = true) {
@@ -37,7 +49,7 @@ struct DevBuf {
     p = cached_malloc(std::max<size_t>(n, 1) * sizeof(T));
     if (!p) return nullptr;
     ptrs.push_back(p);
-    if (copy && n && host) (void)hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice);
+    if (copy && n && host) (void)hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, st);
     return (T*)p;
   }
 };
@@ -239,6 +251,7 @@ int mpsfm_point_covs(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, int32_
   if (int rc = check_device(device)) return rc;
   if (P->n_pts == 0) return 0;
   DevBuf B;
+  if (!B.st) return tfail(MPSFM_EHIP, "hipStreamCreate failed");
   const int32_t* cam = B.up(P->obs_cam, (size_t)P->n_obs);
   const int32_t* pt = B.up(P->obs_pt, (size_t)P->n_obs);
   const double* q = B.up(st->cam_quat_xyzw, (size_t)P->n_cams * 4);
@@ -249,13 +262,13 @@ int mpsfm_point_covs(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, int32_
   double* H = B.up<double>(nullptr, (size_t)P->n_pts * 6, false);
   double* dcov = B.up<double>(nullptr, (size_t)P->n_pts * 9, false);
   if (!cam || !pt || !q || !t || !intr || !iidx || !pts || !H || !dcov) return tfail(MPSFM_ENOMEM, "hipMalloc failed");
-  TRI_TRY(hipMemset(H, 0, sizeof(double) * 6 * (size_t)P->n_pts));
+  TRI_TRY(hipMemsetAsync(H, 0, sizeof(double) * 6 * (size_t)P->n_pts, B.st));
   if (P->n_obs > 0)
-    hipLaunchKernelGGL(k_pcov_accum, dim3((unsigned)((P->n_obs + 255) / 256)), dim3(256), 0, 0, P->n_obs, cam, pt, q, t, intr,
+    hipLaunchKernelGGL(k_pcov_accum, dim3((unsigned)((P->n_obs + 255) / 256)), dim3(256), 0, B.st, P->n_obs, cam, pt, q, t, intr,
                        iidx, pts, P->reproj_loss_magnitude, H);
-  hipLaunchKernelGGL(k_pcov_invert, dim3((P->n_pts + 255) / 256), dim3(256), 0, 0, P->n_pts, H, dcov);
+  hipLaunchKernelGGL(k_pcov_invert, dim3((P->n_pts + 255) / 256), dim3(256), 0, B.st, P->n_pts, H, dcov);
   TRI_TRY(hipGetLastError());
-  TRI_TRY(hipMemcpy(covs, dcov, sizeof(double) * 9 * (size_t)P->n_pts, hipMemcpyDeviceToHost));
+  TRI_TRY(B.down(covs, dcov, sizeof(double) * 9 * (size_t)P->n_pts));
   return 0;
 }
 
@@ -265,13 +278,14 @@ int mpsfm_triangulate_tracks(const mpsfm_tracks* T, int32_t device, double* xyz)
   if (int rc = check_device(device)) return rc;
   if (T->n_tracks == 0) return 0;
   DevBuf B;
+  if (!B.st) return tfail(MPSFM_EHIP, "hipStreamCreate failed");
   TrackArgs a{};
   if (int rc = upload_tracks(T, B, a)) return rc;
   double* dxyz = B.up<double>(nullptr, (size_t)T->n_tracks * 3, false);
   if (!dxyz) return tfail(MPSFM_ENOMEM, "hipMalloc failed");
-  hipLaunchKernelGGL(k_triangulate, dim3((T->n_tracks + 127) / 128), dim3(128), 0, 0, a, dxyz);
+  hipLaunchKernelGGL(k_triangulate, dim3((T->n_tracks + 127) / 128), dim3(128), 0, B.st, a, dxyz);
   TRI_TRY(hipGetLastError());
-  TRI_TRY(hipMemcpy(xyz, dxyz, sizeof(double) * 3 * (size_t)T->n_tracks, hipMemcpyDeviceToHost));
+  TRI_TRY(B.down(xyz, dxyz, sizeof(double) * 3 * (size_t)T->n_tracks));
   return 0;
 }
 
@@ -283,6 +297,7 @@ int mpsfm_filter_tracks(const mpsfm_tracks* T, const double* xyz, int32_t device
   if (T->n_tracks == 0) return 0;
   const int64_t ne = T->track_start[T->n_tracks];
   DevBuf B;
+  if (!B.st) return tfail(MPSFM_EHIP, "hipStreamCreate failed");
   TrackArgs a{};
   if (int rc = upload_tracks(T, B, a)) return rc;
   const double* dxyz = B.up(xyz, (size_t)T->n_tracks * 3);
@@ -290,11 +305,11 @@ int mpsfm_filter_tracks(const mpsfm_tracks* T, const double* xyz, int32_t device
   double* derr = el_sq_err ? B.up<double>(nullptr, (size_t)ne, false) : nullptr;
   uint8_t* dfr = el_front ? B.up<uint8_t>(nullptr, (size_t)ne, false) : nullptr;
   if (!dxyz || (max_tri_angle && !dang) || (el_sq_err && !derr) || (el_front && !dfr)) return tfail(MPSFM_ENOMEM, "hipMalloc failed");
-  hipLaunchKernelGGL(k_filter, dim3((T->n_tracks + 127) / 128), dim3(128), 0, 0, a, dxyz, dang, derr, dfr);
+  hipLaunchKernelGGL(k_filter, dim3((T->n_tracks + 127) / 128), dim3(128), 0, B.st, a, dxyz, dang, derr, dfr);
   TRI_TRY(hipGetLastError());
-  if (dang) TRI_TRY(hipMemcpy(max_tri_angle, dang, sizeof(double) * (size_t)T->n_tracks, hipMemcpyDeviceToHost));
-  if (derr) TRI_TRY(hipMemcpy(el_sq_err, derr, sizeof(double) * (size_t)ne, hipMemcpyDeviceToHost));
-  if (dfr) TRI_TRY(hipMemcpy(el_front, dfr, (size_t)ne, hipMemcpyDeviceToHost));
+  if (dang) TRI_TRY(B.down(max_tri_angle, dang, sizeof(double) * (size_t)T->n_tracks));
+  if (derr) TRI_TRY(B.down(el_sq_err, derr, sizeof(double) * (size_t)ne));
+  if (dfr) TRI_TRY(B.down(el_front, dfr, (size_t)ne));
   return 0;
 }
 

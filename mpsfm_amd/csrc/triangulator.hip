@@ -180,11 +180,13 @@ struct mpsfm_triangulator {
     if (!rc) rc = staged_upload(d_c, cands.data(), sizeof(TriCand) * nc);
     if (!rc) rc = staged_upload(d_v, views.data(), sizeof(TriView) * views.size());
     if (!rc) rc = staged_drain();
+    hipStream_t st = nullptr;  // a pooled non-blocking stream, never the legacy null stream (see DevBuf in tri_kernels.hip)
+    if (!rc && pooled_stream(&st) != hipSuccess) rc = gfail(MPSFM_EHIP, "hipStreamCreate failed");
     if (!rc) {
-      hipLaunchKernelGGL(k_tri_ransac, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, 0, d_c, d_v, (int)nc, d_r);
-      if (hipMemcpy(B.results.data(), d_r, sizeof(TriResult) * nc, hipMemcpyDeviceToHost) != hipSuccess) rc = gfail(MPSFM_EHIP, "reading the RANSAC batch back failed");
+      hipLaunchKernelGGL(k_tri_ransac, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, st, d_c, d_v, (int)nc, d_r);
+      if (hipMemcpyAsync(B.results.data(), d_r, sizeof(TriResult) * nc, hipMemcpyDeviceToHost, st) != hipSuccess) rc = gfail(MPSFM_EHIP, "reading the RANSAC batch back failed");
     }
-    (void)hipStreamSynchronize(nullptr);
+    if (st) { (void)hipStreamSynchronize(st); release_stream(st); }
     cached_free(d_c); cached_free(d_v); cached_free(d_r);
     return rc;
   }

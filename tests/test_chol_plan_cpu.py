@@ -104,6 +104,7 @@ def interpret(P, S, rhs, rng):
         A0 = A.copy()
         t0 = lambda ti, tj: A0[ti * T:(ti + 1) * T, tj * T:(tj + 1) * T]
         written = set()
+        reads = []  # (item index, key) of everything an item reads that it does not own
         Pinv0 = {k: v.copy() for k, v in Pinv.items()}
         for q in rng.permutation(len(items)):
             it = items[q]
@@ -111,7 +112,11 @@ def interpret(P, S, rhs, rng):
                 j, k = it["ti"], it["tk"]
                 assert done_col[j] >= 0 and done_col[j] < l
                 X = Linv[j] if k == j else -Linv[j] @ Pinv0.get((j, k), np.zeros((T, T)))
+                reads.append((q, ("Linv", j)))
+                if k != j:
+                    reads.append((q, ("P", j, k)))
                 for i in rows[it["aux"]:it["aux"] + it["nsrc"]]:
+                    reads.append((q, ("A", int(i), j)))
                     key = ("P", int(i), k)
                     assert key not in written
                     written.add(key)
@@ -124,6 +129,7 @@ def interpret(P, S, rhs, rng):
                 written.add(("A", ti, tk))
                 acc = t0(ti, tk).copy()
                 for c in src:
+                    reads += [(q, ("A", ti, int(c))), (q, ("A", tk, int(c)))]
                     assert done_col[c] >= 0 and done_col[c] < l
                     acc -= t0(ti, int(c)) @ t0(tk, int(c)).T
                 tile(ti, tk)[:] = acc
@@ -131,8 +137,12 @@ def interpret(P, S, rhs, rng):
             # panel tile of column tk
             D = t0(tk, tk).copy()
             X = t0(ti, tk).copy() if ti != tk else None
+            reads.append((q, ("A", tk, tk)))
             for e in src:
                 c, xf = int(e) & 0xffff, bool(int(e) >> 16)
+                reads.append((q, ("A", tk, c)))
+                if X is not None and xf:
+                    reads.append((q, ("A", ti, c)))
                 assert done_col[c] >= 0 and done_col[c] < l
                 D -= t0(tk, c) @ t0(tk, c).T
                 if X is not None and xf:
@@ -140,11 +150,15 @@ def interpret(P, S, rhs, rng):
             Lkk = np.linalg.cholesky(D)
             if ti == tk:
                 Linv[tk] = np.linalg.inv(Lkk)
+                written.add(("Linv", tk))
                 done_col[tk] = l
             else:
                 assert ("A", ti, tk) not in written
                 written.add(("A", ti, tk))
                 tile(ti, tk)[:] = np.linalg.solve(Lkk, X.T).T
+        # no item reads what ANOTHER item of the same launch writes (on the GPU it might see either value)
+        for q, key in reads:
+            assert key not in written, f"launch {l}: item {q} reads {key}, which another item of the launch writes"
     assert (done_col >= 0).all()
     z = A[N, :N].copy()  # forward-substituted rhs
     w = np.concatenate([Linv[i].T @ z[i * T:(i + 1) * T] for i in range(nt)])
