@@ -827,12 +827,11 @@ __global__ __launch_bounds__(kThreads) void k_cost_records(CostArgs A) {
 
 // deterministic column sums (or max for columns flagged in max_mask) of a [rows][stride] array
 constexpr int kReduceThreads = 1024;
-__global__ __launch_bounds__(kReduceThreads) void k_reduce_cols(const double* part, int64_t rows, int stride, int ncols,
-                                                                uint32_t max_mask, double* out, double* out2) {
-  // fixed summation order (thread-strided rows, wave tree, then the 16 wave results in order):
-  // deterministic run to run.  out2 (optional) receives a second copy.
+// fixed summation order (thread-strided rows, wave tree, then the 16 wave results in order): deterministic run to run.
+// out2 (optional) receives a second copy.  s: 8 * kReduceThreads / 64 doubles of LDS, free again on return.
+__device__ __forceinline__ void reduce_cols_block(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out, double* out2,
+                                                  double* s) {
   constexpr int kWaves = kReduceThreads / 64;
-  __shared__ double s[8 * kWaves];
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t r = threadIdx.x; r < rows; r += kReduceThreads) {
 #pragma unroll
@@ -857,6 +856,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_cols(const double* pa
     out[threadIdx.x] = r;
     if (out2) out2[threadIdx.x] = r;
   }
+  __syncthreads();
+}
+__global__ __launch_bounds__(kReduceThreads) void k_reduce_cols(const double* part, int64_t rows, int stride, int ncols,
+                                                                uint32_t max_mask, double* out, double* out2) {
+  __shared__ double s[8 * (kReduceThreads / 64)];
+  reduce_cols_block(part, rows, stride, ncols, max_mask, out, out2, s);
 }
 
 // ---- camera-side kernels ------------------------------------------------------------------------
@@ -1071,7 +1076,50 @@ __device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* sc, con
   next();
 }
 
-// the accepted candidate becomes the state (copies instead of the pointer swaps a host-side loop would do)
+// Single-rank runs: the two partial-sum reductions of an iteration (track sweep: cost, bad count, landmark-gradient maximum;
+// update sweep: candidate cost, bad count, model cost change, step and state norms) and its decision in ONE
+// single-workgroup launch instead of three.
+__global__ __launch_bounds__(kReduceThreads) void k_lm_reduce_decide(const double* part, const double* part2, int64_t rows, LmCtl* C, double* scal,
+                                                                     LmOpts o, LmCtl* host_copy) {
+  __shared__ double s[8 * (kReduceThreads / 64)];
+  const bool live = C->term == kLmRunning;
+  if (live && rows > 0) {
+    reduce_cols_block(part, rows, 4, 3, 1u << 2, scal + U_X_COST, nullptr, s);
+    reduce_cols_block(part2, rows, 8, 5, 0u, scal, nullptr, s);
+  }
+  __threadfence();
+  __syncthreads();
+  if (live && threadIdx.x == 0) lm_decide_thread(C, scal, o);
+  __threadfence();
+  __syncthreads();
+  if (host_copy) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(C);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(host_copy);
+    for (int i = threadIdx.x; i < (int)(sizeof(LmCtl) / 4); i += kReduceThreads) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+  }
+}
+
+// First launch of an iteration: the candidate the previous iteration accepted becomes the state (copies instead of the
+// pointer swaps a host-side loop would do; also in the iteration queued behind the last one, whose other kernels return at
+// once) and the reduced buffer starts from zero.
+__global__ __launch_bounds__(256) void k_lm_prologue(const LmCtl* C, double* red, int64_t nred, int nc, int64_t np, double* q, double* t, double* camtab,
+                                                     double* pts, const double* q2, const double* t2, const double* camtab2, const double* pts2) {
+  const bool acc = C->accepted != 0, live = C->term == kLmRunning;
+  const int64_t n_pts = 3 * np, n_q = 4 * (int64_t)nc, n_t = 3 * (int64_t)nc, n_tab = (int64_t)kCamRec * nc;
+  const int64_t total = acc ? n_pts + n_q + n_t + n_tab : 0;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+  for (int64_t i = i0; i < total; i += step) {
+    if (i < n_pts) pts[i] = pts2[i];
+    else if (i < n_pts + n_q) q[i - n_pts] = q2[i - n_pts];
+    else if (i < n_pts + n_q + n_t) t[i - n_pts - n_q] = t2[i - n_pts - n_q];
+    else camtab[i - n_pts - n_q - n_t] = camtab2[i - n_pts - n_q - n_t];
+  }
+  if (live)
+    for (int64_t i = i0; i < nred; i += step) red[i] = 0.0;
+}
+
+// the accepted candidate becomes the state: after the loop (the iteration that ended the solve may have been accepted)
 __global__ __launch_bounds__(256) void k_lm_accept(const LmCtl* C, int nc, int64_t np, double* q, double* t, double* camtab, double* pts,
                                                    const double* q2, const double* t2, const double* camtab2, const double* pts2) {
   if (!C->accepted) return;  // also after the last iteration: the step that met a tolerance is not taken
@@ -1141,11 +1189,19 @@ void launch_zero(double* p, int64_t n, const LmCtl* ctl, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_zero, dim3((unsigned)std::min<int64_t>(2048, (n + 255) / 256)), dim3(256), 0, s, p, n, ctl);
 }
+void launch_lm_reduce_decide(const double* part, const double* part2, int64_t rows, LmCtl* ctl, double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t s) {
+  hipLaunchKernelGGL(k_lm_reduce_decide, dim3(1), dim3(kReduceThreads), 0, s, part, part2, rows, ctl, scal, o, host_copy);
+}
+void launch_lm_prologue(const LmCtl* ctl, double* red, int64_t nred, int nc, int64_t np, double* q, double* t, double* camtab, double* pts, const double* q2,
+                        const double* t2, const double* camtab2, const double* pts2, hipStream_t s) {
+  const int64_t total = std::max<int64_t>(nred, 3 * np + (int64_t)nc * (4 + 3 + kCamRec));
+  const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+  hipLaunchKernelGGL(k_lm_prologue, dim3(grid), dim3(256), 0, s, ctl, red, nred, nc, np, q, t, camtab, pts, q2, t2, camtab2, pts2);
+}
 void launch_lm_accept(const LmCtl* ctl, int nc, int64_t np, double* q, double* t, double* camtab, double* pts, const double* q2, const double* t2,
                       const double* camtab2, const double* pts2, hipStream_t s) {
   const int64_t total = 3 * np + (int64_t)nc * (4 + 3 + kCamRec);
-  static const int small = [] { const char* e = std::getenv("MPSFM_LM_DBG"); return e ? std::atoi(e) : 0; }();
-  const int grid = (small & 2) ? 1 : (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+  const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
   hipLaunchKernelGGL(k_lm_accept, dim3(grid), dim3(256), 0, s, ctl, nc, np, q, t, camtab, pts, q2, t2, camtab2, pts2);
 }
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t s) {

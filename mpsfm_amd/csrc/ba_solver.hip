@@ -41,6 +41,9 @@ void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const d
                        const int32_t* intr_idx = nullptr, double* camtab2 = nullptr, int* chol_fail = nullptr, const LmCtl* ctl = nullptr);
 void launch_lm_decide(LmCtl* ctl, const double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t);
 void launch_zero(double* p, int64_t n, const LmCtl* ctl, hipStream_t);
+void launch_lm_reduce_decide(const double* part, const double* part2, int64_t rows, LmCtl* ctl, double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t);
+void launch_lm_prologue(const LmCtl* ctl, double* red, int64_t nred, int nc, int64_t np, double* q, double* t, double* camtab, double* pts, const double* q2,
+                        const double* t2, const double* camtab2, const double* pts2, hipStream_t);
 void launch_lm_accept(const LmCtl* ctl, int nc, int64_t np, double* q, double* t, double* camtab, double* pts, const double* q2, const double* t2,
                       const double* camtab2, const double* pts2, hipStream_t);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
@@ -1361,12 +1364,13 @@ static int prepare_scales(mpsfm_ba_handle* h) {
 }
 
 // one track sweep at the current state: fills the reduced buffer and its scalar tail
-static int run_track_sweep(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullptr) {
+// (inside the solve loop the prologue kernel has zeroed the buffer; single-rank runs reduce the partials with the decision)
+static int run_track_sweep(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullptr, bool in_loop = false) {
   hipStream_t s = h->stream;
-  launch_zero(h->d_red, h->red_count, ctl, s);
+  if (!in_loop) launch_zero(h->d_red, h->red_count, ctl, s);
   SweepArgs a = sweep_args(h, radius, ctl);
   launch_track_sweep(a, h->nchunks, false, s);
-  if (h->nchunks + h->nlong > 0)
+  if (h->nchunks + h->nlong > 0 && !(in_loop && !sharded(h)))
     launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, sharded(h) ? nullptr : h->d_scal + U_X_COST);
   if (sharded(h)) launch_gmax_to_slot(h->d_redsc, h->opt.rank > 0 ? h->opt.rank : 0, s);
   h->last_radius = radius;
@@ -1464,13 +1468,13 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   }
   const LmOpts lo{o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.min_relative_decrease, o.max_trust_region_radius,
                   o.min_trust_region_radius, o.max_num_iterations, o.max_num_consecutive_invalid_steps};
-  static const int lm_dbg = [] { const char* e = std::getenv("MPSFM_LM_DBG"); return e ? std::atoi(e) : 0; }();
-  const LmCtl* ctl = (lm_dbg & 1) ? nullptr : h->d_ctl;
-  double host_radius = o.initial_trust_region_radius;
+  const LmCtl* ctl = h->d_ctl;
+  const double host_radius = 0.0;  // unused: the kernels read the radius from the control block
   auto enqueue_iteration = [&](int it) -> int {
     hipEvent_t* ev = (it & 1) ? h->ev2 : h->ev;
     HIP_TRY(hipEventRecord(ev[0], s));
-    if (int rc = run_track_sweep(h, host_radius, ctl)) return rc;
+    launch_lm_prologue(h->d_ctl, h->d_red, h->red_count, h->nc, h->np, h->d_q, h->d_t, h->d_camtab, h->d_pts, h->d_q2, h->d_t2, h->d_camtab2, h->d_pts2, s);
+    if (int rc = run_track_sweep(h, host_radius, ctl, true)) return rc;
     if (int rc = allreduce_dev(h, h->d_red, h->red_count)) return rc;
     HIP_TRY(hipEventRecord(ev[1], s));
     if (int rc = run_dense(h, host_radius, ctl)) return rc;
@@ -1480,13 +1484,16 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     {
       SweepArgs a = sweep_args(h, host_radius, ctl);
       launch_update_sweep(a, h->nchunks, s);
-      if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part2, h->nchunks + h->nlong, 8, 5, 0u, h->d_scal, s);
     }
-    if (int rc = allreduce_dev(h, h->d_scal, 5)) return rc;
-    if (sharded(h))  // the all-reduced scalars of the track sweep (single rank: written by its reduction directly): cost and
-      launch_gmax_from_slots(h->d_redsc, h->d_scal, s);  // bad count summed, landmark-gradient maximum over the rank slots
-    launch_lm_decide(h->d_ctl, h->d_scal, lo, &h->h_ctl[it & 1], s);
-    launch_lm_accept(h->d_ctl, h->nc, h->np, h->d_q, h->d_t, h->d_camtab, h->d_pts, h->d_q2, h->d_t2, h->d_camtab2, h->d_pts2, s);
+    if (!sharded(h)) {
+      launch_lm_reduce_decide(h->d_part, h->d_part2, h->nchunks + h->nlong, h->d_ctl, h->d_scal, lo, &h->h_ctl[it & 1], s);
+    } else {
+      if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part2, h->nchunks + h->nlong, 8, 5, 0u, h->d_scal, s);
+      if (int rc = allreduce_dev(h, h->d_scal, 5)) return rc;
+      // the all-reduced scalars of the track sweep: cost and bad count summed, landmark-gradient maximum over the rank slots
+      launch_gmax_from_slots(h->d_redsc, h->d_scal, s);
+      launch_lm_decide(h->d_ctl, h->d_scal, lo, &h->h_ctl[it & 1], s);
+    }
     HIP_TRY(hipEventRecord(ev[3], s));
     return 0;
   };
@@ -1513,10 +1520,11 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
           std::fprintf(stderr, "[mpsfm_ba] it %3d invalid step (chol_fail=%d mcc=%.3e) radius %.3e\n", it, last.last_chol_fail, last.last_mcc, last.radius);
       }
       (void)prev;
-      host_radius = last.radius;
       if (last.term != kLmRunning) break;
       if (!speculate) { if (int rc = enqueue_iteration(it + 1)) return rc; }
     }
+    // the iteration that ended the solve may have been accepted (iteration or radius limit); the copy is idempotent
+    launch_lm_accept(h->d_ctl, h->nc, h->np, h->d_q, h->d_t, h->d_camtab, h->d_pts, h->d_q2, h->d_t2, h->d_camtab2, h->d_pts2, s);
     HIP_TRY(hipStreamSynchronize(s));  // the iteration queued ahead has drained (every kernel of it returned at once)
   }
   h->last_radius = last.radius;
