@@ -172,9 +172,17 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   for (int i = tid; i < kTileCams * 21; i += kThreads) s_U[i] = 0.0;
   if (tid < kTileCams * 6) { s_gc[tid] = 0.0; s_wv[tid] = 0.0; s_du[tid] = 0.0; }
   if (tid < ncam) s_slot[tid] = A.chunk_cams[H.cam0 + tid];
+  const bool dense = MODE == MODE_FULL && H.dense != 0 && !(A.dbg & 32);
   const bool ents_in_lds = (H.nent <= kEntStage);
-  if (MODE == MODE_FULL && ents_in_lds)
+  // dense chunks: record of every (landmark, local camera), 0xffff: none (256 records need 9 bits).  Lives in the entry
+  // stage, which they do not use.
+  uint16_t* s_rec = reinterpret_cast<uint16_t*>(s_ents);
+  static_assert(kPtsMax * kDenseCams * 2 <= kEntStage * 4, "record table does not fit the entry stage");
+  if (dense) {
+    for (int i = tid; i < kPtsMax * kDenseCams / 2; i += kThreads) s_ents[i] = 0xffffffffu;
+  } else if (MODE == MODE_FULL && ents_in_lds) {
     for (int i = tid; i < H.nent; i += kThreads) s_ents[i] = A.ents[H.ent0 + i];
+  }
   __syncthreads();
   if (A.dbg & 8) return;  // ablation: stop after P0
 
@@ -310,11 +318,84 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
           if (lcam < kTileCams) atomicAdd(&s_wv[lcam * 6 + i], x);
           else atomicAdd(&A.wv[(size_t)slot * 6 + i], x);
         }
+        if (dense && my_bad == 0) s_rec[lpt * kDenseCams + lcam] = (uint16_t)tid;  // this record's Z takes part in the products
       }
     }
 
     __syncthreads();  // the rows of s_W now hold Z
 
+
+    // ---- P3b, dense chunks: S[ci,cj] -= Z_ci Z_cj^T for all local camera pairs at once as M M^T on the matrix pipe -----
+    // M is the (6 ncam) x (3 npt) matrix of the chunk's Z blocks (zero where a camera does not see a landmark; cameras of a
+    // chunk see most of its landmarks, so the dense product is barely more arithmetic than the pair list).  48 rows = three
+    // 16-row tiles, six tile pairs; the K index of an instruction is a LANDMARK (the four lane quarters feed four
+    // consecutive landmarks, one coordinate per instruction); the four waves split the landmarks and add their partial
+    // tiles into the packed 6x6 blocks in LDS.  Against six lanes per block summing a pair list on the vector pipe
+    // (LDS-bandwidth-bound: 126 doubles read per pair) this reads 9 doubles per lane and four landmarks.
+    if (dense) {
+      typedef double v4d __attribute__((ext_vector_type(4)));
+      const int lane = tid & 63, wave = tid >> 6;
+      const int rc = lane & 15, kq = lane >> 4;
+      for (int i = tid; i < (kDenseCams * (kDenseCams + 1) / 2) * 36; i += kThreads) s_stage[i] = 0.0;
+      int cam_of[3], a3_of[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { const int r = 16 * t + rc; cam_of[t] = r / 6; a3_of[t] = (r - 6 * cam_of[t]) * 3; }
+      v4d acc[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+      __syncthreads();
+      if (!(A.dbg & 2))
+        for (int g = wave; 4 * g < npt; g += kThreads / 64) {
+          const int p = 4 * g + kq;
+          double x[3][3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int rec = p < npt ? (int)s_rec[p * kDenseCams + cam_of[t]] : 0xffff;
+            const double* z = &s_W[(rec == 0xffff ? 0 : rec) * kWStride + a3_of[t]];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const double v = z[c]; x[t][c] = rec == 0xffff ? 0.0 : v; }
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[0][c], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[1][c], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[2][c], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[1][c], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[2][c], acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2][c], x[2][c], acc[5], 0, 0, 0);
+          }
+        }
+      // accumulator element r of lane l: row (l >> 4) + 4 r, column l & 15 of its tile pair
+      {
+        const int tis[6] = {0, 0, 0, 1, 1, 2}, tjs[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * tis[q] + kq + 4 * r, col = 16 * tjs[q] + rc;
+            const int ci = row / 6, cj = col / 6;
+            if (cj < ncam && ci <= cj) {
+              const double v = acc[q][r];
+              if (v != 0.0) atomicAdd(&s_stage[(cj * (cj + 1) / 2 + ci) * 36 + (row - 6 * ci) * 6 + (col - 6 * cj)], v);
+            }
+          }
+      }
+      __syncthreads();
+      if (!(A.dbg & 4)) {
+        const int nb = ncam * (ncam + 1) / 2;
+        for (int idx = tid; idx < nb * 36; idx += kThreads) {
+          const int b = idx / 36, el = idx - b * 36;
+          int cj = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+          while (cj * (cj + 1) / 2 > b) --cj;
+          while ((cj + 1) * (cj + 2) / 2 <= b) ++cj;
+          const int ci = b - cj * (cj + 1) / 2;
+          const int ra = el / 6, cb = el - ra * 6;
+          const double v = s_stage[idx];
+          if (v != 0.0 && (ci != cj || cb >= ra))  // diagonal blocks keep their upper triangle only
+            atomicAdd(&A.Sblk[sky_block(A.sky, s_slot[ci], s_slot[cj]) * 36 + el], -v);
+        }
+      }
+    } else
     // ---- P3b: Schur pairs, block-major:  S[ci,cj] -= sum_pairs Z_i Z_j^T  (= W_i (V+D)^-1 W_j^T) ---------
     // Rounds of kGroups blocks: six lanes sum one block in registers, park it in LDS, then the whole
     // workgroup flushes the round with lanes running along the 36 contiguous doubles of a block

@@ -943,6 +943,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       double nvarpts = 0;
     };
     const int nch = (int)chunks.size();
+    const bool dense_on = !(std::getenv("MPSFM_SWEEP_DENSE") && std::atoi(std::getenv("MPSFM_SWEEP_DENSE")) == 0);
     const int cparts = std::max(1, std::min(host_threads(), nch / 48));
     std::vector<ChunkPart> cp((size_t)cparts);
     run_parts(cparts, [&](int t, int nparts) {
@@ -955,6 +956,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
         const int32_t* cams = chunk_cams.data() + H.cam0;
         const int64_t c_first = H.pt0, end_pt = (int64_t)H.pt0 + H.npt;
         pe.clear();
+        bool dup = false;    // two records of one camera for one variable landmark
         int64_t w = H.rec0;  // next record
         for (int64_t k = c_first; k < end_pt; ++k) {
           const int p = order[k];
@@ -984,6 +986,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
                 const uint32_t lj = rec_meta[(size_t)H.rec0 + rbase + j] & 0xff;
                 pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + i) | ((uint32_t)(rbase + j) << 8) | (lpt << 16)});
                 // two records of one camera: the diagonal block needs B + B^T
+                if (li == lj && i != j) dup = true;
                 if (li == lj && i != j)
                   pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + j) | ((uint32_t)(rbase + i) << 8) | (lpt << 16)});
               }
@@ -1013,6 +1016,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
         items.clear();
         for (const auto& bo : blk_order)
           for (int q = 0; q < bo.first; q += kItemPairs) items.emplace_back(std::min(kItemPairs, bo.first - q), bo.second + q);
+        H.dense = (H.ncam <= kDenseCams && !dup && dense_on) ? 1 : 0;
+        H.pad_ = 0;
         H.blk0 = (int32_t)C.blk_desc.size();  // thread-local for now
         H.ent0 = (int32_t)C.ents.size();
         H.nent = (int32_t)pe.size();
@@ -1087,11 +1092,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
 
   lap("chunks + pair tables");
   if (h->opt.verbose >= 2 && !chunks.empty()) {
-    double sr = 0, sp = 0, sc = 0, sb = 0, se = 0; int mb = 0, mc = 0;
-    for (const ChunkHdr& H : chunks) { sr += H.nrec; sp += H.npt; sc += H.ncam; sb += H.nblk; se += H.nent; mb = std::max(mb, H.nblk); mc = std::max(mc, H.ncam); }
+    double sr = 0, sp = 0, sc = 0, sb = 0, se = 0, sd = 0; int mb = 0, mc = 0;
+    for (const ChunkHdr& H : chunks) { sr += H.nrec; sp += H.npt; sc += H.ncam; sb += H.nblk; se += H.nent; sd += H.dense; mb = std::max(mb, H.nblk); mc = std::max(mc, H.ncam); }
     const double n = (double)chunks.size();
-    std::fprintf(stderr, "[mpsfm_ba] build: %zu chunks; per chunk: %.1f records, %.1f landmarks, %.1f cameras (max %d), %.1f work items (max %d), %.1f pairs\n",
-                 chunks.size(), sr / n, sp / n, sc / n, mc, sb / n, mb, se / n);
+    std::fprintf(stderr, "[mpsfm_ba] build: %zu chunks; per chunk: %.1f records, %.1f landmarks, %.1f cameras (max %d), %.1f work items (max %d), %.1f pairs; %.0f %% of the chunks take the dense product\n",
+                 chunks.size(), sr / n, sp / n, sc / n, mc, sb / n, mb, se / n, 100.0 * sd / n);
   }
   // -- which 6x6 blocks of S exist, and the tables of the dense factorisation
   if (use_graph) {

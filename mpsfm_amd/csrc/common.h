@@ -52,7 +52,11 @@ struct ChunkHdr {
   int32_t cam0, ncam;    // local camera list in chunk_cams[cam0 ..)
   int32_t blk0, nblk;    // Schur work items (a destination block of S + a run of its pairs) of this chunk
   int32_t ent0, nent;    // the chunk's pair entries
+  int32_t dense;         // 1: at most kDenseCams local cameras and one record per (camera, variable landmark): Schur products as one
+                         //    small dense product on the matrix pipe (k_track_sweep), the pair tables are not used
+  int32_t pad_;
 };
+constexpr int kDenseCams = 8;  // 8 cameras x 6 rows = 48 rows = three 16-row MFMA tiles
 
 // A landmark whose track does not fit a chunk (more than kObsMax records or kLocalCamsMax cameras)
 // is swept by a workgroup of its own that strides over the records (k_long_track_sweep).
