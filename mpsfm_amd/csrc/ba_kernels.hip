@@ -1118,6 +1118,10 @@ __device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* sc, con
     const double gmax = fmax(sc[U_GMAX_CAMS], sc[U_GMAX_PTS]);
     if (gmax <= o.gradient_tolerance) { C->term = MPSFM_TERM_GRADIENT_TOLERANCE; C->iter -= 1; C->n_cost_evals -= 1; return; }
   }
+  if (C->iter == 1) {  // the iteration and radius limits are looked at after iteration 0 (cost and gradient at the start) was evaluated
+    if (o.max_iterations <= 0) { C->term = MPSFM_TERM_MAX_ITERATIONS; C->iter = 0; C->n_cost_evals -= 1; return; }
+    if (C->radius <= o.min_radius) { C->term = MPSFM_TERM_MIN_RADIUS; C->iter = 0; C->n_cost_evals -= 1; return; }
+  }
   const double mcc = sc[U_MCC];
   C->last_mcc = mcc;
   const bool solver_ok = !x_bad && chol_fail == 0 && isfinite(mcc);

@@ -732,7 +732,10 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     for (const auto& B : gb) for (size_t w = 0; w < B.size(); ++w) graph.bits[w] |= B[w];
     if (sharded(h)) {
       // union over the ranks through the sum exchange: E indicator digits per double in base (world + 1)
-      const int world = std::max(h->opt.world_size, 2);
+      // the number of ranks from the exchange itself (a hook may come without world_size)
+      double ones = 1.0;
+      if (int rc = allreduce_host(h, &ones, 1)) return rc;
+      const int world = std::max((int)std::llround(ones), 1);
       int E = 1;
       { double cap = 9007199254740992.0 / (world + 1); while (cap >= (world + 1) && E < 16) { cap /= (world + 1); ++E; } }
       const int64_t nbits = (int64_t)ncv_real * ncv_real;
@@ -1465,8 +1468,6 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     std::memset(&c0, 0, sizeof(c0));
     c0.radius = o.initial_trust_region_radius; c0.decrease_factor = 2.0; c0.x_norm = x_norm; c0.fixed_cost = fixed;
     c0.term = kLmRunning; c0.check_gradient = 1;
-    if (o.max_num_iterations <= 0) c0.term = MPSFM_TERM_MAX_ITERATIONS;
-    else if (c0.radius <= o.min_trust_region_radius) c0.term = MPSFM_TERM_MIN_RADIUS;
     h->h_ctl[0] = c0;
     HIP_TRY(hipMemcpyAsync(h->d_ctl, &h->h_ctl[0], sizeof(LmCtl), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));  // the pinned slot is reused below
@@ -1505,7 +1506,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   LmCtl last = h->h_ctl[0];
   if (last.term == kLmRunning) {
     if (int rc = enqueue_iteration(1)) return rc;
-    static const bool speculate = [] { const char* e = std::getenv("MPSFM_LM_SPECULATE"); return !(e && std::atoi(e) == 0); }();
+    const bool speculate = [] { const char* e = std::getenv("MPSFM_LM_SPECULATE"); return !(e && std::atoi(e) == 0); }();  // per solve: tests switch it
     for (int it = 1;; ++it) {
       if (speculate) { if (int rc = enqueue_iteration(it + 1)) return rc; }  // ahead of the news about iteration `it`
       hipEvent_t* ev = (it & 1) ? h->ev2 : h->ev;

@@ -306,13 +306,23 @@ def test_c2_reprojection_only_full_size():
     np.testing.assert_allclose(pg.pts, po.pts, rtol=1e-5, atol=1e-6)
 
 
-def test_max_iterations_and_tight_tolerances():
+@pytest.mark.parametrize("speculate", ["1", "0"])
+def test_max_iterations_and_tight_tolerances(speculate, monkeypatch):
+    """Termination by the iteration limit right after an accepted step (the state must be that step's candidate: the
+    device-side loop copies it in the launch that FOLLOWS the decision), by tight tolerances, and by the radius limit; with
+    the host one iteration ahead of the device (default) and waiting for every decision (MPSFM_LM_SPECULATE=0)."""
+    monkeypatch.setenv("MPSFM_LM_SPECULATE", speculate)
     prob, _ = make_scene(7, 400, True, seed=43)
-    for kw in (dict(max_num_iterations=3), dict(function_tolerance=1e-12, parameter_tolerance=1e-12, max_num_iterations=80)):
+    for kw in (dict(max_num_iterations=3), dict(max_num_iterations=1), dict(function_tolerance=1e-12, parameter_tolerance=1e-12, max_num_iterations=80),
+               dict(min_trust_region_radius=2e4), dict(max_num_iterations=0)):
         pg, po = prob.copy(), prob.copy()
         sg, so = capi.ba_solve(pg, capi.default_options(**kw)), O.solve(po, O.default_options(**kw))
-        assert sg["num_iterations"] == so["num_iterations"] and sg["termination"] == so["termination"]
-        assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+        assert sg["num_iterations"] == so["num_iterations"] and sg["termination"] == so["termination"], kw
+        assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8), kw
+        assert sg["trace_accepted"] == so["trace_accepted"], kw
+        np.testing.assert_allclose(pg.cam_t, po.cam_t, rtol=0, atol=1e-9, err_msg=str(kw))
+        np.testing.assert_allclose(pg.cam_quat, po.cam_quat, rtol=0, atol=1e-9, err_msg=str(kw))
+        np.testing.assert_allclose(pg.pts, po.pts, rtol=0, atol=1e-8, err_msg=str(kw))
 
 
 @pytest.mark.parametrize("collective", ["rccl", "hook"])
