@@ -11,6 +11,7 @@
 //                   landmarks and the candidate cost in one pass over the same chunks.
 #include "common.h"
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 
 namespace mpsfm {
@@ -1076,18 +1077,24 @@ void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t s) { 
 // radius rule of LevenbergMarquardtStrategy, the bookkeeping the summary reports.  The reference reaches this loop through
 // pyceres.solve (mpsfm/sfm/mapper/bundle_adjustment.py:285-293) with Ceres' default options.
 __device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* sc, const LmOpts& o);
+// The host's copy of the control block, written straight into its pinned slot (device-visible host memory).  While the
+// solve runs only the head travels (the host looks at the termination code and the diagnostics); the traces follow with the
+// decision that ends the solve.
+__device__ __forceinline__ void lm_copy_to_host(const LmCtl* C, LmCtl* host_copy) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(C);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(host_copy);
+  const bool over = __hip_atomic_load(&C->term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kLmRunning;
+  const int n = (int)((over ? sizeof(LmCtl) : offsetof(LmCtl, trace_cost)) / 4);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence_system();
+}
 __global__ __launch_bounds__(64) void k_lm_decide(LmCtl* C, const double* sc, LmOpts o, LmCtl* host_copy) {
   const bool live = C->term == kLmRunning;
   if (live && threadIdx.x == 0) lm_decide_thread(C, sc, o);
   __threadfence();
   __syncthreads();
   // the host's copy of the block goes straight into its pinned slot (device-visible host memory): no copy command in the loop
-  if (host_copy) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(C);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(host_copy);
-    for (int i = threadIdx.x; i < (int)(sizeof(LmCtl) / 4); i += 64) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-  }
+  if (host_copy) lm_copy_to_host(C, host_copy);
 }
 __device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* sc, const LmOpts& o) {
   auto trace = [&](double cost, double rad, int acc) {
@@ -1177,12 +1184,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_lm_reduce_decide(const doubl
   if (live && threadIdx.x == 0) lm_decide_thread(C, scal, o);
   __threadfence();
   __syncthreads();
-  if (host_copy) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(C);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(host_copy);
-    for (int i = threadIdx.x; i < (int)(sizeof(LmCtl) / 4); i += kReduceThreads) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-  }
+  if (host_copy) lm_copy_to_host(C, host_copy);
 }
 
 // First launch of an iteration: the candidate the previous iteration accepted becomes the state (copies instead of the
