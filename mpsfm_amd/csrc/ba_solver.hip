@@ -740,8 +740,20 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       { double cap = 9007199254740992.0 / (world + 1); while (cap >= (world + 1) && E < 16) { cap /= (world + 1); ++E; } }
       const int64_t nbits = (int64_t)ncv_real * ncv_real;
       std::vector<double> packed((size_t)((nbits + E - 1) / E), 0.0);
-      for (int64_t q = 0; q < nbits; ++q)
-        if (graph.get((int)(q / ncv_real), (int)(q % ncv_real))) packed[(size_t)(q / E)] += std::pow((double)(world + 1), (double)(q % E));
+      double pw[16];
+      pw[0] = 1.0;
+      for (int e = 1; e < 16; ++e) pw[e] = pw[e - 1] * (double)(world + 1);
+      for (int a = 0; a < ncv_real; ++a) {
+        const uint64_t* row = graph.row(a);
+        for (int w = 0; w < graph.words; ++w) {
+          uint64_t m = row[w];
+          while (m) {
+            const int64_t q = (int64_t)a * ncv_real + (w * 64 + __builtin_ctzll(m));
+            m &= m - 1;
+            packed[(size_t)(q / E)] += pw[q % E];
+          }
+        }
+      }
       if (int rc = allreduce_host(h, packed.data(), (int64_t)packed.size())) return rc;
       for (size_t w = 0; w < packed.size(); ++w) {
         double v = packed[w];

@@ -16,7 +16,7 @@ constexpr int kSegAlign = 16;    // slots per alignment unit: 16 cameras x 6 col
 constexpr int kMoveUpMax = 4;    // a segment with this many cameras beyond a multiple of 16 hands them to its parent instead of padding
 constexpr int kMinLeaf = 32;     // no dissection below this many cameras
 constexpr int kMinBfsLevels = 5;
-constexpr double kMaxPlanProducts = 2.0e7;  // tile products beyond which no item table is built (~0.5 GB of tables)
+constexpr double kMaxPlanProducts = 3.0e6;  // tile products beyond which no item table is built (tens of MB of tables, seconds to build)
 
 using Mask = std::vector<uint64_t>;
 
