@@ -993,7 +993,21 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
           if (!P->pt_const[p]) {
             pt_kv[(size_t)k] = (uint16_t)kv;
             C.nvarpts += 1;
+            // two records of one camera for this landmark (records are slot-sorted: they are neighbours)
+            for (int i = 1; i < kv; ++i)
+              if ((rec_meta[(size_t)H.rec0 + rbase + i] & 0xff) == (rec_meta[(size_t)H.rec0 + rbase + i - 1] & 0xff)) dup = true;
+          }
+        }
+        // Chunks that form their Schur blocks as one dense product (k_track_sweep) need no pair tables at all.
+        H.dense = (H.ncam <= kDenseCams && !dup && dense_on) ? 1 : 0;
+        H.pad_ = 0;
+        if (!H.dense) {
+          for (int64_t k = c_first; k < end_pt; ++k) {
+            const int p = order[k];
+            if (P->pt_const[p]) continue;
             // Schur pairs of this landmark: records rbase .. rbase+kv-1 have variable cameras (slot-sorted)
+            const int rbase = pt_rec_start[(size_t)k] - H.rec0;
+            const int kv = (int)pt_kv[(size_t)k];
             const uint32_t lpt = (uint32_t)(k - c_first);
             for (int i = 0; i < kv; ++i) {
               const uint32_t li = rec_meta[(size_t)H.rec0 + rbase + i] & 0xff;
@@ -1001,7 +1015,6 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
                 const uint32_t lj = rec_meta[(size_t)H.rec0 + rbase + j] & 0xff;
                 pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + i) | ((uint32_t)(rbase + j) << 8) | (lpt << 16)});
                 // two records of one camera: the diagonal block needs B + B^T
-                if (li == lj && i != j) dup = true;
                 if (li == lj && i != j)
                   pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + j) | ((uint32_t)(rbase + i) << 8) | (lpt << 16)});
               }
@@ -1031,8 +1044,6 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
         items.clear();
         for (const auto& bo : blk_order)
           for (int q = 0; q < bo.first; q += kItemPairs) items.emplace_back(std::min(kItemPairs, bo.first - q), bo.second + q);
-        H.dense = (H.ncam <= kDenseCams && !dup && dense_on) ? 1 : 0;
-        H.pad_ = 0;
         H.blk0 = (int32_t)C.blk_desc.size();  // thread-local for now
         H.ent0 = (int32_t)C.ents.size();
         H.nent = (int32_t)pe.size();
@@ -1138,6 +1149,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     for (int c = 0; c < ncv; ++c) first_blk[(size_t)c] = c;
     for (const ChunkHdr& H : chunks) {
       const int32_t* cams = chunk_cams.data() + H.cam0;
+      if (H.dense)  // no pair table: every pair of the chunk's (sorted) cameras may be coupled
+        for (int q = 1; q < H.ncam; ++q) first_blk[(size_t)cams[q]] = std::min(first_blk[(size_t)cams[q]], cams[0]);
       for (int b = 0; b < H.nblk; ++b) {
         const uint32_t d = blk_desc[(size_t)H.blk0 + (size_t)b];
         const int si = cams[d & 0xff], sj = cams[(d >> 8) & 0xff];
