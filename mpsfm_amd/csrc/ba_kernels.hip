@@ -1084,7 +1084,7 @@ __device__ __forceinline__ void lm_copy_to_host(const LmCtl* C, LmCtl* host_copy
   const uint32_t* src = reinterpret_cast<const uint32_t*>(C);
   uint32_t* dst = reinterpret_cast<uint32_t*>(host_copy);
   const bool over = __hip_atomic_load(&C->term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kLmRunning;
-  const int n = (int)((over ? sizeof(LmCtl) : offsetof(LmCtl, trace_cost)) / 4);
+  const int n = (int)((over ? sizeof(LmCtl) : sizeof(LmHead)) / 4);
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __threadfence_system();
 }
@@ -1096,76 +1096,86 @@ __global__ __launch_bounds__(64) void k_lm_decide(LmCtl* C, const double* sc, Lm
   // the host's copy of the block goes straight into its pinned slot (device-visible host memory): no copy command in the loop
   if (host_copy) lm_copy_to_host(C, host_copy);
 }
-__device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* sc, const LmOpts& o) {
+// The head of the block and the iteration's scalars are pulled into registers first and the head is written back once: as a
+// chain of dependent global loads and stores the same logic took ~15 us.
+__device__ __forceinline__ void lm_decide_logic(LmHead& L, LmCtl* C, const double (&sc)[U_COUNT], const LmOpts& o) {
   auto trace = [&](double cost, double rad, int acc) {
-    if (C->trace_len < MPSFM_MAX_TRACE) {
-      C->trace_cost[C->trace_len] = cost; C->trace_radius[C->trace_len] = rad; C->trace_accepted[C->trace_len] = (uint8_t)acc; C->trace_len++;
+    if (L.trace_len < MPSFM_MAX_TRACE) {
+      C->trace_cost[L.trace_len] = cost; C->trace_radius[L.trace_len] = rad; C->trace_accepted[L.trace_len] = (uint8_t)acc; L.trace_len++;
     }
   };
   auto next = [&]() {  // the tests at the top of the next iteration
-    if (C->term != kLmRunning) return;
-    if (C->iter >= o.max_iterations) C->term = MPSFM_TERM_MAX_ITERATIONS;
-    else if (C->radius <= o.min_radius) C->term = MPSFM_TERM_MIN_RADIUS;
+    if (L.term != kLmRunning) return;
+    if (L.iter >= o.max_iterations) L.term = MPSFM_TERM_MAX_ITERATIONS;
+    else if (L.radius <= o.min_radius) L.term = MPSFM_TERM_MIN_RADIUS;
   };
-  C->accepted = 0;
-  C->iter += 1; C->n_jac_evals += 1; C->n_cost_evals += 1;
+  L.accepted = 0;
+  L.iter += 1; L.n_jac_evals += 1; L.n_cost_evals += 1;
   const int chol_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;
-  C->last_chol_fail = chol_fail;
+  L.last_chol_fail = chol_fail;
   const double x_cost = sc[U_X_COST];
   const bool x_bad = sc[U_X_BAD] > 0.0;  // residual not evaluable or a landmark block not positive definite
-  C->last_x_cost = x_cost;
-  if (C->iter == 1) {
-    if (!isfinite(x_cost) || x_bad) { C->term = kLmNumericError; return; }
-    C->initial_cost = x_cost + C->fixed_cost;
-    C->cur_cost = x_cost;
-    trace(x_cost + C->fixed_cost, C->radius, 1);
+  L.last_x_cost = x_cost;
+  if (L.iter == 1) {
+    if (!isfinite(x_cost) || x_bad) { L.term = kLmNumericError; return; }
+    L.initial_cost = x_cost + L.fixed_cost;
+    L.cur_cost = x_cost;
+    trace(x_cost + L.fixed_cost, L.radius, 1);
   }
-  if (C->check_gradient) {  // Ceres checks the gradient tolerance at iteration 0 and after each successful step
-    C->check_gradient = 0;
+  if (L.check_gradient) {  // Ceres checks the gradient tolerance at iteration 0 and after each successful step
+    L.check_gradient = 0;
     const double gmax = fmax(sc[U_GMAX_CAMS], sc[U_GMAX_PTS]);
-    if (gmax <= o.gradient_tolerance) { C->term = MPSFM_TERM_GRADIENT_TOLERANCE; C->iter -= 1; C->n_cost_evals -= 1; return; }
+    if (gmax <= o.gradient_tolerance) { L.term = MPSFM_TERM_GRADIENT_TOLERANCE; L.iter -= 1; L.n_cost_evals -= 1; return; }
   }
-  if (C->iter == 1) {  // the iteration and radius limits are looked at after iteration 0 (cost and gradient at the start) was evaluated
-    if (o.max_iterations <= 0) { C->term = MPSFM_TERM_MAX_ITERATIONS; C->iter = 0; C->n_cost_evals -= 1; return; }
-    if (C->radius <= o.min_radius) { C->term = MPSFM_TERM_MIN_RADIUS; C->iter = 0; C->n_cost_evals -= 1; return; }
+  if (L.iter == 1) {  // the iteration and radius limits are looked at after iteration 0 (cost and gradient at the start) was evaluated
+    if (o.max_iterations <= 0) { L.term = MPSFM_TERM_MAX_ITERATIONS; L.iter = 0; L.n_cost_evals -= 1; return; }
+    if (L.radius <= o.min_radius) { L.term = MPSFM_TERM_MIN_RADIUS; L.iter = 0; L.n_cost_evals -= 1; return; }
   }
   const double mcc = sc[U_MCC];
-  C->last_mcc = mcc;
+  L.last_mcc = mcc;
   const bool solver_ok = !x_bad && chol_fail == 0 && isfinite(mcc);
   if (!(solver_ok && mcc > 0.0)) {
-    C->invalid_run += 1; C->n_unsuccess += 1;
-    if (C->invalid_run >= o.max_invalid_steps) C->term = MPSFM_TERM_INVALID_STEPS;
-    C->radius /= C->decrease_factor; C->decrease_factor *= 2.0;
-    trace(C->cur_cost + C->fixed_cost, C->radius, 0);
-    C->last_cand = DBL_MAX; C->last_rel = 0.0; C->last_step_norm = 0.0;
+    L.invalid_run += 1; L.n_unsuccess += 1;
+    if (L.invalid_run >= o.max_invalid_steps) L.term = MPSFM_TERM_INVALID_STEPS;
+    L.radius /= L.decrease_factor; L.decrease_factor *= 2.0;
+    trace(L.cur_cost + L.fixed_cost, L.radius, 0);
+    L.last_cand = DBL_MAX; L.last_rel = 0.0; L.last_step_norm = 0.0;
     next();
     return;
   }
-  C->invalid_run = 0;
+  L.invalid_run = 0;
   const double cand = (sc[U_BAD] > 0.0 || !isfinite(sc[U_CAND_COST])) ? DBL_MAX : sc[U_CAND_COST];
   const double step_norm = sqrt(sc[U_STEP_SQ_PTS] + sc[U_STEP_SQ_CAMS]);
-  C->last_cand = cand; C->last_step_norm = step_norm;
-  if (step_norm <= o.parameter_tolerance * (C->x_norm + o.parameter_tolerance)) { C->term = MPSFM_TERM_PARAMETER_TOLERANCE; return; }
+  L.last_cand = cand; L.last_step_norm = step_norm;
+  if (step_norm <= o.parameter_tolerance * (L.x_norm + o.parameter_tolerance)) { L.term = MPSFM_TERM_PARAMETER_TOLERANCE; return; }
   const double cost_change = x_cost - cand;
-  if (fabs(cost_change) <= o.function_tolerance * x_cost) { C->term = MPSFM_TERM_FUNCTION_TOLERANCE; return; }
+  if (fabs(cost_change) <= o.function_tolerance * x_cost) { L.term = MPSFM_TERM_FUNCTION_TOLERANCE; return; }
   const double rel = cost_change / mcc;
-  C->last_rel = rel;
+  L.last_rel = rel;
   if (rel > o.min_relative_decrease) {
-    C->accepted = 1;
-    C->x_norm = sqrt(sc[U_XN_SQ_PTS] + sc[U_XN_SQ_CAMS]);
-    C->cur_cost = cand;
+    L.accepted = 1;
+    L.x_norm = sqrt(sc[U_XN_SQ_PTS] + sc[U_XN_SQ_CAMS]);
+    L.cur_cost = cand;
     const double u = 2.0 * rel - 1.0;
-    C->radius = fmin(o.max_radius, C->radius / fmax(1.0 / 3.0, 1.0 - u * u * u));
-    C->decrease_factor = 2.0;
-    C->n_success += 1;
-    C->check_gradient = 1;
-    trace(cand + C->fixed_cost, C->radius, 1);
+    L.radius = fmin(o.max_radius, L.radius / fmax(1.0 / 3.0, 1.0 - u * u * u));
+    L.decrease_factor = 2.0;
+    L.n_success += 1;
+    L.check_gradient = 1;
+    trace(cand + L.fixed_cost, L.radius, 1);
   } else {
-    C->radius /= C->decrease_factor; C->decrease_factor *= 2.0;
-    C->n_unsuccess += 1;
-    trace(C->cur_cost + C->fixed_cost, C->radius, 0);
+    L.radius /= L.decrease_factor; L.decrease_factor *= 2.0;
+    L.n_unsuccess += 1;
+    trace(L.cur_cost + L.fixed_cost, L.radius, 0);
   }
   next();
+}
+__device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* scal, const LmOpts& o) {
+  double sc[U_COUNT];
+#pragma unroll
+  for (int i = 0; i < U_COUNT; ++i) sc[i] = scal[i];
+  LmHead L = *static_cast<const LmHead*>(C);
+  lm_decide_logic(L, C, sc, o);
+  *static_cast<LmHead*>(C) = L;
 }
 
 // Single-rank runs: the two partial-sum reductions of an iteration (track sweep: cost, bad count, landmark-gradient maximum;

@@ -95,11 +95,13 @@ enum {
 // host enqueues iteration i+1 while iteration i still runs and only reads a copy of this block one iteration late: no
 // stream synchronisation inside the loop.  Every kernel of an iteration returns at once when `term` says the solve is
 // over (the one iteration enqueued ahead of the news).
-struct LmCtl {
+struct LmHead {  // what travels to the host every iteration
   double radius, decrease_factor, x_norm, cur_cost, fixed_cost, initial_cost;
   double last_x_cost, last_cand, last_rel, last_step_norm, last_mcc;  // diagnostics of the last decided iteration
   int32_t term;          // kLmRunning, MPSFM_TERM_* once decided, kLmNumericError: the initial point cannot be evaluated
   int32_t iter, invalid_run, check_gradient, accepted, n_success, n_unsuccess, n_cost_evals, n_jac_evals, last_chol_fail, trace_len, pad_;
+};
+struct LmCtl : LmHead {
   double trace_cost[MPSFM_MAX_TRACE], trace_radius[MPSFM_MAX_TRACE];
   uint8_t trace_accepted[MPSFM_MAX_TRACE];
 };
