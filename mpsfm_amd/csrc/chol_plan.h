@@ -52,7 +52,8 @@ struct CholPlan {
 };
 
 // Tile pattern: nt x nt bytes, pat[ti * nt + tj] != 0 for ti > tj: tile (ti, tj) of S can be nonzero.
-void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, int inv_rows, CholPlan& P);
+// tables = false: symbolic factorisation, levels and the cost estimate only (plan_auto compares candidates that way)
+void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, int inv_rows, CholPlan& P, bool tables = true);
 // slot order from the camera graph.  depth < 0: caller's order; depth >= 0: nested dissection of that depth (0: components + RCM)
 void order_cameras(const CamGraph& g, int depth, std::vector<int32_t>& slot_of_nat, int& nslots);
 void tile_pattern(const CamGraph& g, const std::vector<int32_t>& slot_of_nat, int nslots, std::vector<uint8_t>& pat, int& nt);

@@ -209,7 +209,7 @@ void tile_pattern(const CamGraph& g, const std::vector<int32_t>& slot_of_nat, in
   }
 }
 
-void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, int inv_rows, CholPlan& P) {
+void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, int inv_rows, CholPlan& P, bool tables) {
   P.nt = nt; P.use_pinv = use_pinv;
   P.struct_start.assign((size_t)nt + 1, 0); P.struct_rows.clear();
   P.parent.assign((size_t)nt, -1); P.level.assign((size_t)nt, 0);
@@ -252,6 +252,19 @@ void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, i
     if (prod > kMaxPlanProducts) {
       P.products = (int64_t)prod; P.nlevels = 0; P.est_us = 1e30;
       P.launch_start.assign(1, 0); P.back_start.assign(1, 0);
+      return;
+    }
+    if (!tables) {  // candidate comparison: every column's struct(j) (struct(j) + 1) / 2 tile products, roles over the subtree sizes
+      P.products = (int64_t)prod;
+      if (use_pinv) {
+        std::vector<int64_t> sub((size_t)nt, 1);
+        for (int j = 0; j < nt; ++j) {
+          if (P.parent[(size_t)j] >= 0) sub[(size_t)P.parent[(size_t)j]] += sub[(size_t)j];
+          const int64_t nrr = P.struct_start[(size_t)j + 1] - P.struct_start[(size_t)j] - 1;
+          P.roles += sub[(size_t)j] * ((nrr + inv_rows - 1) / std::max(inv_rows, 1));
+        }
+      }
+      P.est_us = 9.5 * P.nlevels + 0.02 * (double)P.products + 0.004 * (double)P.roles + (use_pinv ? 10.0 : 6.5 * P.nlevels);
       return;
     }
   }
@@ -337,6 +350,7 @@ void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_ti
   for (int s = g.n; s >= kMinLeaf; s /= 2) ++dmax;  // parts of at least kMinLeaf cameras are worth cutting again
   dmax = std::min(dmax, 5);
   bool have = false;
+  std::vector<uint8_t> best_pat;
   for (int d = -1; d <= (forced ? -1 : dmax); ++d) {
     const int depth = forced ? forced_depth : d;
     CholPlan P;
@@ -346,9 +360,10 @@ void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_ti
     std::vector<uint8_t> pat;
     int nt = 0;
     tile_pattern(g, P.slot_of_nat, P.nslots, pat, nt);
-    plan_from_pattern(pat, nt, nt <= pinv_max_tiles, inv_rows, P);
-    if (!have || P.est_us < best.est_us - 1e-9) { best = std::move(P); have = true; }
+    plan_from_pattern(pat, nt, nt <= pinv_max_tiles, inv_rows, P, /*tables=*/false);
+    if (!have || P.est_us < best.est_us - 1e-9) { best = std::move(P); best_pat = std::move(pat); have = true; }
   }
+  plan_from_pattern(best_pat, best.nt, best.nt <= pinv_max_tiles, inv_rows, best, /*tables=*/true);
   best.nat_of_slot.assign((size_t)best.nslots, -1);
   for (int i = 0; i < g.n; ++i) best.nat_of_slot[(size_t)best.slot_of_nat[(size_t)i]] = i;
 }
