@@ -609,102 +609,42 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   };
   struct MergePart {
     int p0 = 0, p1 = 0, err = 0;
+    std::vector<int64_t> pstart;  // block range of every landmark of the part
+    std::vector<Blk> blks;
     std::vector<Rec> recs, fixed;
     std::vector<int32_t> fixed_pt;
     std::vector<int64_t> nrec_of;  // records per landmark of the range
   };
   const int mparts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (P->n_obs + P->n_dobs) / 32768));  // starting threads only pays above ~100 k blocks
   std::vector<MergePart> mp((size_t)mparts);
+  // Phase A (host threads over landmark ranges): the blocks of every landmark side by side (counting sort).
   run_parts(mparts, [&](int t, int nparts) {
     MergePart& M = mp[(size_t)t];
     M.p0 = (int)((int64_t)npu * t / nparts); M.p1 = (int)((int64_t)npu * (t + 1) / nparts);
     const int p0 = M.p0, np_loc = M.p1 - M.p0;
-    std::vector<int64_t> pstart((size_t)np_loc + 1, 0);
+    std::vector<int64_t>& pstart = M.pstart;
+    pstart.assign((size_t)np_loc + 1, 0);
     for (int64_t i = 0; i < P->n_obs; ++i) { const unsigned q = (unsigned)(P->obs_pt[i] - p0); if (q < (unsigned)np_loc) pstart[q + 1]++; }
     for (int64_t i = 0; i < P->n_dobs; ++i) { const unsigned q = (unsigned)(P->dobs_pt[i] - p0); if (q < (unsigned)np_loc) pstart[q + 1]++; }
     for (int q = 0; q < np_loc; ++q) pstart[q + 1] += pstart[q];
-    std::vector<Blk> blks((size_t)pstart[np_loc]);
-    {
-      std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
-      for (int64_t i = 0; i < P->n_obs; ++i) {
-        const unsigned q = (unsigned)(P->obs_pt[i] - p0);
-        if (q >= (unsigned)np_loc) continue;
-        const int c = P->obs_cam[i];
-        blks[fill[q]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 0, i};
-      }
-      for (int64_t i = 0; i < P->n_dobs; ++i) {
-        const unsigned q = (unsigned)(P->dobs_pt[i] - p0);
-        if (q >= (unsigned)np_loc) continue;
-        const int c = P->dobs_cam[i];
-        if (!(P->dobs_depth[i] > 0.0)) { M.err = 1; return; }
-        blks[fill[q]++] = Blk{c, slot[c] < 0 ? INT32_MAX : slot[c], 1, i};
-      }
+    M.blks.resize((size_t)pstart[np_loc]);
+    std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
+    for (int64_t i = 0; i < P->n_obs; ++i) {
+      const unsigned q = (unsigned)(P->obs_pt[i] - p0);
+      if (q >= (unsigned)np_loc) continue;
+      M.blks[(size_t)fill[q]++] = Blk{P->obs_cam[i], 0, 0, i};
     }
-    M.recs.reserve(blks.size());
-    M.nrec_of.assign((size_t)np_loc, 0);
-    for (int q = 0; q < np_loc; ++q) {
-      const int p = p0 + q;
-      auto b0 = blks.begin() + pstart[q], b1 = blks.begin() + pstart[q + 1];
-      std::sort(b0, b1, [](const Blk& x, const Blk& y) {
-        if (x.key != y.key) return x.key < y.key;
-        if (x.cam != y.cam) return x.cam < y.cam;
-        if (x.kind != y.kind) return x.kind < y.kind;
-        return x.src < y.src;
-      });
-      const size_t before = M.recs.size();
-      for (auto it = b0; it != b1;) {
-        auto je = it;
-        while (je != b1 && je->cam == it->cam) ++je;
-        auto mid = it;
-        while (mid != je && mid->kind == 0) ++mid;
-        const int64_t nr = mid - it, nd = je - mid;
-        const bool is_fixed = (slot[it->cam] < 0) && P->pt_const[p];
-        for (int64_t k = 0; k < std::max(nr, nd); ++k) {
-          Rec r{it->cam, slot[it->cam], 0, 0, 0, 1.0, 0.0, 1.0};
-          if (k < nr) { const int64_t s = (it + k)->src; r.flags |= kRecHasReproj; r.u = P->obs_xy[2 * s]; r.v = P->obs_xy[2 * s + 1]; }
-          if (k < nd) {
-            const int64_t s = (mid + k)->src;
-            r.flags |= kRecHasDepth; r.d = deff(it->cam, s); r.m = P->dobs_magnitude[s]; r.a = P->dobs_param[s];
-            if (!(r.d > 0.0)) { M.err = 2; return; }
-          }
-          if (is_fixed) { M.fixed.push_back(r); M.fixed_pt.push_back(p); }
-          else M.recs.push_back(r);
-        }
-        it = je;
-      }
-      M.nrec_of[(size_t)q] = (int64_t)(M.recs.size() - before);
+    for (int64_t i = 0; i < P->n_dobs; ++i) {
+      const unsigned q = (unsigned)(P->dobs_pt[i] - p0);
+      if (q >= (unsigned)np_loc) continue;
+      if (!(P->dobs_depth[i] > 0.0)) { M.err = 1; return; }
+      M.blks[(size_t)fill[q]++] = Blk{P->dobs_cam[i], 0, 1, i};
     }
   });
-  for (const MergePart& M : mp) {
+  for (const MergePart& M : mp)
     if (M.err == 1) return fail(MPSFM_EINVAL, "depth prior must be positive");
-    if (M.err == 2) return fail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive");
-  }
-  lap("group + merge (threads)");
-  std::vector<int64_t> prec((size_t)npu + 1, 0);  // record range per caller landmark
-  std::vector<Rec> recs;
-  std::vector<Rec> fixed;
-  std::vector<int32_t> fixed_pt;
-  {
-    std::vector<int64_t> base((size_t)mparts + 1, 0);
-    for (int t = 0; t < mparts; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)mp[(size_t)t].recs.size();
-    recs.resize((size_t)base[(size_t)mparts]);
-    run_parts(mparts, [&](int t, int) {
-      MergePart& M = mp[(size_t)t];
-      std::copy(M.recs.begin(), M.recs.end(), recs.begin() + base[(size_t)t]);
-      int64_t o = base[(size_t)t];
-      for (int q = 0; q < M.p1 - M.p0; ++q) { prec[(size_t)(M.p0 + q)] = o; o += M.nrec_of[(size_t)q]; }
-      std::vector<Rec>().swap(M.recs);
-    });
-    prec[(size_t)npu] = base[(size_t)mparts];
-    for (MergePart& M : mp) {
-      fixed.insert(fixed.end(), M.fixed.begin(), M.fixed.end());
-      fixed_pt.insert(fixed_pt.end(), M.fixed_pt.begin(), M.fixed_pt.end());
-    }
-  }
-  h->nfixed = (int64_t)fixed.size();
-  h->nblocks_total = P->n_obs + P->n_dobs;
+  lap("group blocks by landmark (threads)");
 
-  lap("merge records");
   // -- camera order.  Up to kIndexMaxSlots variable cameras: the camera graph (who shares a variable landmark with whom,
   //    summed over the ranks) decides the slot order — nested dissection when it shortens the dependent chain of the tile
   //    factorisation (chol_plan.h) — and which 6x6 blocks of S exist.  Beyond: the caller's order and a block skyline.
@@ -712,16 +652,19 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   CamGraph graph;
   if (use_graph) {
     graph.init(ncv_real);
-    const int gparts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)recs.size() / 65536));
-    std::vector<std::vector<uint64_t>> gb((size_t)gparts);
-    run_parts(gparts, [&](int t, int nparts) {
+    std::vector<std::vector<uint64_t>> gb((size_t)mparts);
+    run_parts(mparts, [&](int t, int) {
+      const MergePart& M = mp[(size_t)t];
       std::vector<uint64_t>& B = gb[(size_t)t];
       B.assign(graph.bits.size(), 0);
       std::vector<int32_t> sl;
-      for (int p = (int)((int64_t)npu * t / nparts); p < (int)((int64_t)npu * (t + 1) / nparts); ++p) {
-        if (P->pt_const[p]) continue;
+      for (int q = 0; q < M.p1 - M.p0; ++q) {
+        if (P->pt_const[M.p0 + q]) continue;
         sl.clear();
-        for (int64_t r = prec[p]; r < prec[p + 1]; ++r) if (recs[r].slot >= 0 && (sl.empty() || sl.back() != recs[r].slot)) sl.push_back(recs[r].slot);
+        for (int64_t r = M.pstart[(size_t)q]; r < M.pstart[(size_t)q + 1]; ++r) {
+          const int sc = slot[(size_t)M.blks[(size_t)r].cam];
+          if (sc >= 0 && std::find(sl.begin(), sl.end(), sc) == sl.end()) sl.push_back(sc);  // a handful of cameras per landmark
+        }
         for (size_t a = 0; a < sl.size(); ++a)
           for (size_t b = a + 1; b < sl.size(); ++b) {
             B[(size_t)sl[a] * graph.words + (sl[b] >> 6)] |= 1ull << (sl[b] & 63);
@@ -776,28 +719,83 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     h->ncv = h->plan.nslots;
     h->n = 6 * h->ncv;
     h->nt = (h->n + 31) / 32;
-    bool changed = false;
     for (int i = 0; i < nc; ++i)
-      if (slot[(size_t)i] >= 0) { const int s2 = h->plan.slot_of_nat[(size_t)slot[(size_t)i]]; changed = changed || s2 != slot[(size_t)i]; slot[(size_t)i] = s2; }
-    if (changed) {
-      // records of a landmark stay sorted by (slot, camera); constant cameras last
-      parallel_ranges((int64_t)npu, 4096, [&](int64_t p0, int64_t p1) {
-        for (int64_t p = p0; p < p1; ++p) {
-          for (int64_t r = prec[(size_t)p]; r < prec[(size_t)p + 1]; ++r) recs[(size_t)r].slot = slot[(size_t)recs[(size_t)r].cam];
-          std::stable_sort(recs.begin() + prec[(size_t)p], recs.begin() + prec[(size_t)p + 1], [](const Rec& a, const Rec& b) {
-            const int ka = a.slot < 0 ? INT32_MAX : a.slot, kb = b.slot < 0 ? INT32_MAX : b.slot;
-            if (ka != kb) return ka < kb;
-            return a.cam < b.cam;
-          });
-        }
-      });
-      for (Rec& r : fixed) r.slot = slot[(size_t)r.cam];
-      lap("records in the new camera order");
-    }
+      if (slot[(size_t)i] >= 0) slot[(size_t)i] = h->plan.slot_of_nat[(size_t)slot[(size_t)i]];
   } else {
     h->nat_slot.resize((size_t)ncv_real);
     for (int i = 0; i < ncv_real; ++i) h->nat_slot[(size_t)i] = i;
   }
+
+  // Phase B (the same host threads): every landmark's blocks ordered by (final) camera slot, a reprojection and a depth
+  // block of one (camera, landmark) pair merged into one record.
+  run_parts(mparts, [&](int t, int) {
+    MergePart& M = mp[(size_t)t];
+    const int p0 = M.p0, np_loc = M.p1 - M.p0;
+    std::vector<Blk>& blks = M.blks;
+    for (Blk& bk : blks) bk.key = slot[(size_t)bk.cam] < 0 ? INT32_MAX : slot[(size_t)bk.cam];
+    M.recs.reserve(blks.size());
+    M.nrec_of.assign((size_t)np_loc, 0);
+    for (int q = 0; q < np_loc; ++q) {
+      const int p = p0 + q;
+      auto b0 = blks.begin() + M.pstart[(size_t)q], b1 = blks.begin() + M.pstart[(size_t)q + 1];
+      std::sort(b0, b1, [](const Blk& x, const Blk& y) {
+        if (x.key != y.key) return x.key < y.key;
+        if (x.cam != y.cam) return x.cam < y.cam;
+        if (x.kind != y.kind) return x.kind < y.kind;
+        return x.src < y.src;
+      });
+      const size_t before = M.recs.size();
+      for (auto it = b0; it != b1;) {
+        auto je = it;
+        while (je != b1 && je->cam == it->cam) ++je;
+        auto mid = it;
+        while (mid != je && mid->kind == 0) ++mid;
+        const int64_t nr = mid - it, nd = je - mid;
+        const bool is_fixed = (slot[it->cam] < 0) && P->pt_const[p];
+        for (int64_t k = 0; k < std::max(nr, nd); ++k) {
+          Rec r{it->cam, slot[it->cam], 0, 0, 0, 1.0, 0.0, 1.0};
+          if (k < nr) { const int64_t s = (it + k)->src; r.flags |= kRecHasReproj; r.u = P->obs_xy[2 * s]; r.v = P->obs_xy[2 * s + 1]; }
+          if (k < nd) {
+            const int64_t s = (mid + k)->src;
+            r.flags |= kRecHasDepth; r.d = deff(it->cam, s); r.m = P->dobs_magnitude[s]; r.a = P->dobs_param[s];
+            if (!(r.d > 0.0)) { M.err = 2; return; }
+          }
+          if (is_fixed) { M.fixed.push_back(r); M.fixed_pt.push_back(p); }
+          else M.recs.push_back(r);
+        }
+        it = je;
+      }
+      M.nrec_of[(size_t)q] = (int64_t)(M.recs.size() - before);
+    }
+    std::vector<Blk>().swap(M.blks);
+  });
+  for (const MergePart& M : mp)
+    if (M.err == 2) return fail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive");
+  lap("sort + merge into records (threads)");
+  std::vector<int64_t> prec((size_t)npu + 1, 0);  // record range per caller landmark
+  HostBuf<Rec> recs;  // uninitialised: value-initialising tens of MB on one thread costs milliseconds
+  std::vector<Rec> fixed;
+  std::vector<int32_t> fixed_pt;
+  {
+    std::vector<int64_t> base((size_t)mparts + 1, 0);
+    for (int t = 0; t < mparts; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)mp[(size_t)t].recs.size();
+    recs.alloc((size_t)base[(size_t)mparts]);
+    run_parts(mparts, [&](int t, int) {
+      MergePart& M = mp[(size_t)t];
+      std::copy(M.recs.begin(), M.recs.end(), recs.data() + base[(size_t)t]);
+      int64_t o = base[(size_t)t];
+      for (int q = 0; q < M.p1 - M.p0; ++q) { prec[(size_t)(M.p0 + q)] = o; o += M.nrec_of[(size_t)q]; }
+      std::vector<Rec>().swap(M.recs);
+    });
+    prec[(size_t)npu] = base[(size_t)mparts];
+    for (MergePart& M : mp) {
+      fixed.insert(fixed.end(), M.fixed.begin(), M.fixed.end());
+      fixed_pt.insert(fixed_pt.end(), M.fixed_pt.begin(), M.fixed_pt.end());
+    }
+  }
+  h->nfixed = (int64_t)fixed.size();
+  h->nblocks_total = P->n_obs + P->n_dobs;
+  lap("merge records");
   // -- landmark order: those with records sorted by their camera-slot list, then the rest that
   //    are referenced by fixed blocks only
   std::vector<int32_t> order; order.reserve(npu);
