@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
         else if (br < bc) v = P.Sblk[sky_block(P.sky, br, bc) * 36 + a * 6 + b];
         else if (br > bc) v = P.Sblk[sky_block(P.sky, bc, br) * 36 + b * 6 + a];
         else v = P.Sblk[sky_block(P.sky, br, br) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
-        if (R == C) v += fmin(fmax(P.diagU[R], P.min_diag), P.max_diag) / lm_radius;
+        // an alignment slot (no camera: not even its diagonal block exists) is an identity row, whatever the damping options
+        if (R == C) v += sky_has(P.sky, br, br) ? fmin(fmax(P.diagU[R], P.min_diag), P.max_diag) / lm_radius : 1.0;
       }
     }
     T[e] = v;
