@@ -128,6 +128,15 @@ int dissect(Sub& S, std::vector<Seg>& tree, const std::vector<int>& nodes, int d
       if (bm > 0) {
         std::vector<int> A(order.begin(), order.begin() + ls[(size_t)bm]), B(order.begin() + ls[(size_t)bm + 1], order.end()),
             sep(order.begin() + ls[(size_t)bm], order.begin() + ls[(size_t)bm + 1]);
+        // cameras of the level that see nothing beyond it are not needed in the separator: a level is as wide as the LONGEST
+        // link out of the level before it, most cameras reach less far
+        {
+          S.set_nodes(B);
+          std::vector<int> keep;
+          for (int v : sep) { if (S.degree(v) > 0) keep.push_back(v); else A.push_back(v); }
+          if (!keep.empty()) sep.swap(keep);
+          else { for (size_t q = 0; q < sep.size(); ++q) A.pop_back(); }  // (a level without forward links cannot be a middle level)
+        }
         std::sort(A.begin(), A.end()); std::sort(B.begin(), B.end()); std::sort(sep.begin(), sep.end());
         const int ca = dissect(S, tree, A, depth - 1);
         const int cb = dissect(S, tree, B, depth - 1);
