@@ -1086,13 +1086,12 @@ __device__ __forceinline__ void lm_copy_to_host(const LmCtl* C, LmCtl* host_copy
   const bool over = __hip_atomic_load(&C->term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kLmRunning;
   const int n = (int)((over ? sizeof(LmCtl) : sizeof(LmHead)) / 4);
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __threadfence_system();
+  // no fence: the end of the kernel releases at system scope, and the host only looks after the event behind it
 }
 __global__ __launch_bounds__(64) void k_lm_decide(LmCtl* C, const double* sc, LmOpts o, LmCtl* host_copy) {
   const bool live = C->term == kLmRunning;
   if (live && threadIdx.x == 0) lm_decide_thread(C, sc, o);
-  __threadfence();
-  __syncthreads();
+  __syncthreads();  // one workgroup: the barrier's workgroup-scope release / acquire orders thread 0's stores before the copy
   // the host's copy of the block goes straight into its pinned slot (device-visible host memory): no copy command in the loop
   if (host_copy) lm_copy_to_host(C, host_copy);
 }
@@ -1172,7 +1171,7 @@ __device__ __forceinline__ void lm_decide_logic(LmHead& L, LmCtl* C, const doubl
 __device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* scal, const LmOpts& o) {
   double sc[U_COUNT];
 #pragma unroll
-  for (int i = 0; i < U_COUNT; ++i) sc[i] = scal[i];
+  for (int i = 0; i < U_COUNT; ++i) sc[i] = __hip_atomic_load(scal + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past this CU's L1
   LmHead L = *static_cast<const LmHead*>(C);
   lm_decide_logic(L, C, sc, o);
   *static_cast<LmHead*>(C) = L;
@@ -1189,10 +1188,10 @@ __global__ __launch_bounds__(kReduceThreads) void k_lm_reduce_decide(const doubl
     reduce_cols_block(part, rows, 4, 3, 1u << 2, scal + U_X_COST, nullptr, s);
     reduce_cols_block(part2, rows, 8, 5, 0u, scal, nullptr, s);
   }
-  __threadfence();
+  // One workgroup: barriers (workgroup-scope release / acquire) order the reductions' stores, the deciding thread's loads
+  // (write-through reads, below) and the copy; agent-scope fences here cost an L2 write-back each (2-6 us).
   __syncthreads();
   if (live && threadIdx.x == 0) lm_decide_thread(C, scal, o);
-  __threadfence();
   __syncthreads();
   if (host_copy) lm_copy_to_host(C, host_copy);
 }
