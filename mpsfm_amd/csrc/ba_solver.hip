@@ -370,6 +370,7 @@ struct mpsfm_ba_handle {
   CholPlan plan;                    // camera order, tile elimination tree and launch tables of the dense factorisation (chol_plan.h)
   LevelPlanDev lp;
   CholItem* d_lp_items = nullptr;
+  uint8_t* d_lp_live = nullptr;
   int32_t *d_lp_srcs = nullptr, *d_lp_rows = nullptr, *d_lp_struct_start = nullptr, *d_lp_struct_rows = nullptr, *d_lp_back_cols = nullptr, *d_lp_asm = nullptr;
   std::vector<int32_t> nat_slot;    // variable camera in the caller's order -> slot (the accessors of S and y speak the caller's order)
   int n_user = 0;                   // 6 x variable cameras: the reduced dimension the caller sees (n also counts dummy slots)
@@ -434,7 +435,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
                   h->d_sky_first, h->d_sky_start, h->d_sky_index,
-                  h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm};
+                  h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm, h->d_lp_live};
   for (void* p : ptrs) cached_free(p);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
   release_pinned(h->h_scal);
@@ -552,11 +553,16 @@ static int upload_plan(mpsfm_ba_handle* h, int64_t nblk) {
   if ((rc2 = dev_upload(&h->d_lp_struct_rows, PL.struct_rows))) return rc2;
   if ((rc2 = dev_upload(&h->d_lp_back_cols, PL.back_cols))) return rc2;
   if ((rc2 = dev_upload(&h->d_lp_asm, PL.asm_tiles))) return rc2;
+  {
+    std::vector<uint8_t> live((size_t)(PL.nt + 1) * (size_t)(PL.nt + 2) / 2, 0);
+    for (int32_t id : PL.asm_tiles) live[(size_t)id] = 1;
+    if ((rc2 = dev_upload(&h->d_lp_live, live))) return rc2;
+  }
   LevelPlanDev& D = h->lp;
   D.valid = PL.nt >= 1 && PL.nlevels >= 1; D.use_pinv = PL.use_pinv;
   D.d_items = h->d_lp_items; D.d_srcs = h->d_lp_srcs; D.d_rows = h->d_lp_rows;
   D.d_struct_start = h->d_lp_struct_start; D.d_struct_rows = h->d_lp_struct_rows; D.d_back_cols = h->d_lp_back_cols;
-  D.d_asm_tiles = h->d_lp_asm; D.n_asm = (int32_t)PL.asm_tiles.size(); D.nlevels = PL.nlevels;
+  D.d_asm_tiles = h->d_lp_asm; D.d_tile_live = h->d_lp_live; D.n_asm = (int32_t)PL.asm_tiles.size(); D.nlevels = PL.nlevels;
   D.h_launch_start = PL.launch_start.data(); D.h_back_start = PL.back_start.data();
   if (h->opt.verbose >= 2)
     std::fprintf(stderr, "[mpsfm_ba] build: camera order: %s (depth %d), %d slots for %d cameras, %d tile columns in %d levels, %lld tile products, %lld inverse roles, %d blocks of S\n",
@@ -1417,7 +1423,8 @@ static int run_dense(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullp
     double* pinv = dense_pinv(h->d_dwork, h->nt, &h->ov, &h->lp);
     const bool listed = level && !pinv;
     AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius,
-                    h->opt.min_lm_diagonal, h->opt.max_lm_diagonal, h->d_A, pinv, listed ? h->lp.d_asm_tiles : nullptr, listed ? h->lp.n_asm : 0, ctl};
+                    h->opt.min_lm_diagonal, h->opt.max_lm_diagonal, h->d_A, pinv, listed ? h->lp.d_asm_tiles : nullptr, listed ? h->lp.n_asm : 0,
+                    (level && pinv) ? h->lp.d_tile_live : nullptr, ctl};
     launch_assemble(as, s);
     launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->lp, ctl);
   }

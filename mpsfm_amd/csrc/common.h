@@ -321,6 +321,7 @@ struct LevelPlanDev {
   const int32_t* d_struct_rows = nullptr;
   const int32_t* d_back_cols = nullptr;
   const int32_t* d_asm_tiles = nullptr;
+  const uint8_t* d_tile_live = nullptr;  // [(nt+1)(nt+2)/2] 1 for the tiles in d_asm_tiles
   int32_t n_asm = 0, nlevels = 0;
   const int32_t* h_launch_start = nullptr;  // host: [nlevels + 1]
   const int32_t* h_back_start = nullptr;    // host: [nlevels + 1]
@@ -335,6 +336,8 @@ struct AssembleArgs {
   double* Pinv;  // accumulators of the inverse propagation (same tile indexing as A), zeroed here; may be NULL
   const int32_t* tile_list;  // packed ids of the tiles to assemble (one workgroup each), NULL: all (nt+1)(nt+2)/2
   int32_t n_list;
+  const uint8_t* live;       // all tiles launched (inverse accumulators to zero): per packed id, 0 = the factorisation never
+                             // reads this tile of A, skip the gather; NULL: every tile is assembled
   const LmCtl* ctl;  // as in SweepArgs
 };
 

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
   // the accumulators of the inverse propagation (see k_chol_step) start from zero
   if (P.Pinv && ti < P.nt && tj < ti)
     for (int e = threadIdx.x; e < kTileElems; e += 256) P.Pinv[id * kTileElems + e] = 0.0;
+  if (P.live && !P.live[id]) return;  // outside the symbolic factor: nobody reads this tile
   for (int e = threadIdx.x; e < kTileElems; e += 256) {
     const int r = e >> 5, c = e & 31;
     const int C = tj * kTile + c;
