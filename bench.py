@@ -134,7 +134,7 @@ def main():
         "peak": 78.6, "unit": "TFLOP/s", "traffic": None, "algorithmic_flops": flops_dense, "avg_ms": dense_ms, "n": n,
         # one dense solve = this many launches; avg_ms is the HIP-event time of the whole sequence, to be compared with
         # sum(launches x rocprofv3 AverageNs) from profiles/rNN_kernel_stats.csv
-        "launches_per_solve": ({"k_assemble": 1, "k_chol_level": plan["levels"], "k_inv_w": 1, "k_inv_y": 1} if plan["inverse_accumulators"] else
+        "launches_per_solve": ({"k_assemble": 1, "k_chol_level": plan["levels"], "k_inv_y": 1} if plan["inverse_accumulators"] else
                                {"k_assemble": 1, "k_chol_level": plan["levels"], "k_back_level": plan["backsub_launches"]}),
         "plan": plan,
         # the factorisation only touches the tiles the symbolic factorisation marks (camera pairs that share landmarks, plus

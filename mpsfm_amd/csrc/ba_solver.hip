@@ -1424,7 +1424,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullp
     const bool listed = level && !pinv;
     AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius,
                     h->opt.min_lm_diagonal, h->opt.max_lm_diagonal, h->d_A, pinv, listed ? h->lp.d_asm_tiles : nullptr, listed ? h->lp.n_asm : 0,
-                    (level && pinv) ? h->lp.d_tile_live : nullptr, ctl};
+                    (level && pinv) ? h->d_yc : nullptr, (level && pinv) ? h->lp.d_tile_live : nullptr, ctl};
     launch_assemble(as, s);
     launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->lp, ctl);
   }
@@ -1773,7 +1773,7 @@ int mpsfm_ba_dense_plan(mpsfm_ba_handle* h, int64_t info[10]) {
   const bool level = dense_level(&h->ov, &h->lp);
   const bool pinv = level && dense_pinv(h->d_dwork, h->nt, &h->ov, &h->lp) != nullptr;
   const int64_t v[10] = {h->ncv, h->nt, level ? P.nlevels : h->nt, P.nd_depth, pinv ? 1 : 0, (int64_t)P.items.size(), P.products, P.roles, h->sblk_blocks,
-                         pinv ? 2 : (level ? P.nlevels : (h->nt + 3) / 4 + 1)};
+                         pinv ? 1 : (level ? P.nlevels : (h->nt + 3) / 4 + 1)};
   for (int i = 0; i < 10; ++i) info[i] = v[i];
   return 0;
 }

@@ -336,6 +336,7 @@ struct AssembleArgs {
   double* Pinv;  // accumulators of the inverse propagation (same tile indexing as A), zeroed here; may be NULL
   const int32_t* tile_list;  // packed ids of the tiles to assemble (one workgroup each), NULL: all (nt+1)(nt+2)/2
   int32_t n_list;
+  double* y;                 // solution vector, zeroed here when the back substitution accumulates into it (else NULL)
   const uint8_t* live;       // all tiles launched (inverse accumulators to zero): per packed id, 0 = the factorisation never
                              // reads this tile of A, skip the gather; NULL: every tile is assembled
   const LmCtl* ctl;  // as in SweepArgs

@@ -31,6 +31,8 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
   // the accumulators of the inverse propagation (see k_chol_step) start from zero
   if (P.Pinv && ti < P.nt && tj < ti)
     for (int e = threadIdx.x; e < kTileElems; e += 256) P.Pinv[id * kTileElems + e] = 0.0;
+  if (P.y && blockIdx.x == 0)  // the solution vector is accumulated with atomics (k_inv_y): start from zero
+    for (int e = threadIdx.x; e < n; e += 256) P.y[e] = 0.0;
   if (P.live && !P.live[id]) return;  // outside the symbolic factor: nobody reads this tile
   for (int e = threadIdx.x; e < kTileElems; e += 256) {
     const int r = e >> 5, c = e & 31;
@@ -740,33 +742,35 @@ __global__ __launch_bounds__(256) void k_backsub_group(const double* A, const do
   }
 }
 
-// ---- y = L^-T z from the inverse accumulators (two launches) --------------------------------------------
-// w_i = L(i,i)^-T z_i, z_i = row 0 of the right-hand-side tile (nt, i); y starts as w
-__global__ __launch_bounds__(64) void k_inv_w(const double* A, const double* LinvT, int nt, int n, double* wbuf, double* y, const LmCtl* ctl) {
-  if (lm_over(ctl)) return;
-  const int i = blockIdx.x, r = threadIdx.x & 31, h = threadIdx.x >> 5;
-  const double* z = A + lt_tile(nt, i) * kTileElems;
-  const double* Li = LinvT + (size_t)i * kTileElems + r * kTile;
-  double sacc = 0.0;
-#pragma unroll
-  for (int c = 16 * h; c < 16 * h + 16; ++c) sacc += Li[c] * z[c];
-  sacc += __shfl_down(sacc, 32, 64);
-  if (threadIdx.x < 32) {
-    wbuf[i * kTile + r] = sacc;
-    if (i * kTile + r < n) y[i * kTile + r] = sacc;
-  }
-}
-// y_k -= sum_{i>k, i = k+1+s (mod kInvSplit)} P(i,k)^T w_i : the long columns are cut into kInvSplit workgroups
+// ---- y = L^-T z from the inverse accumulators (one launch) ----------------------------------------------
+// y_k = w_k - sum_{i>k} P(i,k)^T w_i,  w_i = L(i,i)^-T z_i,  z_i = row 0 of the right-hand-side tile (nt, i).  The long columns
+// are cut into kInvSplit workgroups (i = k+1+s mod kInvSplit); every workgroup first forms the w_i it needs itself (a
+// 32 x 32 product each — cheaper than a launch of its own for them), split 0 also w_k.  y starts from zero (k_assemble).
 constexpr int kInvSplit = 4;
-__global__ __launch_bounds__(256) void k_inv_y(const double* Pinv, const double* wbuf, int nt, int n, double* y, const LmCtl* ctl) {
+__global__ __launch_bounds__(256) void k_inv_y(const double* A, const double* LinvT, const double* Pinv, int nt, int n, double* y, const LmCtl* ctl) {
+  __shared__ double s_w[(kPlainMaxTiles / kInvSplit + 2) * kTile];
   __shared__ double s_part[8][kTile];
   if (lm_over(ctl)) return;
-  const int k = blockIdx.x, c = threadIdx.x & 31, part = threadIdx.x >> 5;
-  if (k + 1 + (int)blockIdx.y >= nt) return;
+  const int k = blockIdx.x, sp = blockIdx.y, c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int first = k + 1 + sp;
+  const int m = first < nt ? (nt - first + kInvSplit - 1) / kInvSplit : 0;  // tiles i = first + kInvSplit j
+  const int own = sp == 0 ? 1 : 0;                                          // slot 0: w_k
+  if (m + own == 0) return;
+  for (int idx = threadIdx.x; idx < (m + own) * kTile; idx += 256) {
+    const int slot = idx >> 5, r = idx & 31;
+    const int i = (own && slot == 0) ? k : first + kInvSplit * (slot - own);
+    const double* z = A + lt_tile(nt, i) * kTileElems;
+    const double* Li = LinvT + (size_t)i * kTileElems + r * kTile;
+    double sacc = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < kTile; ++q) sacc = __builtin_fma(Li[q], z[q], sacc);
+    s_w[idx] = sacc;
+  }
+  __syncthreads();
   double sacc = 0.0;
-  for (int i = k + 1 + (int)blockIdx.y; i < nt; i += kInvSplit) {
-    const double* Pt = Pinv + lt_tile(i, k) * kTileElems;
-    const double* w = wbuf + i * kTile;
+  for (int j = 0; j < m; ++j) {
+    const double* Pt = Pinv + lt_tile(first + kInvSplit * j, k) * kTileElems;
+    const double* w = s_w + (j + own) * kTile;
 #pragma unroll
     for (int r = 4 * part; r < 4 * part + 4; ++r) sacc += Pt[r * kTile + c] * w[r];
   }
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(256) void k_inv_y(const double* Pinv, const double*
 #pragma unroll
     for (int q = 0; q < 8; ++q) v += s_part[q][c];
     const int g = k * kTile + c;
-    if (g < n) atomicAdd(&y[g], -v);
+    if (g < n) atomicAdd(&y[g], (own ? s_w[c] : 0.0) - v);
   }
 }
 
@@ -834,8 +838,7 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
       hipLaunchKernelGGL(k_chol_level, dim3((unsigned)grid), dim3(kStepThreads), 0, s, G);
     }
     if (Pinv) {
-      hipLaunchKernelGGL(k_inv_w, dim3(nt), dim3(64), 0, s, A, LinvT, nt, n, wbuf, y, ctl);
-      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, Pinv, wbuf, nt, n, y, ctl);
+      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, A, LinvT, Pinv, nt, n, y, ctl);
       return;
     }
     for (int l = 0; l < lp->nlevels; ++l) {
