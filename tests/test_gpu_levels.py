@@ -38,6 +38,14 @@ def test_every_slot_order_solves_the_same_system(variant, orbit, monkeypatch):
         monkeypatch.setenv(k, v)
     with capi.BAHandle(prob.copy()) as h:
         assert h.reduced_dim == 6 * (prob.n_cams - 1)
+        plan = h.dense_plan()
+        assert plan["slots"] >= prob.n_cams - 1 and plan["tile_columns"] == (6 * plan["slots"] + 31) // 32
+        assert 1 <= plan["levels"] <= plan["tile_columns"]
+        if variant in ("callers_order", "no_graph_skyline"):
+            assert plan["nd_depth"] == -1 and plan["slots"] == prob.n_cams - 1 and plan["levels"] == plan["tile_columns"]
+        if variant in ("auto", "depth1", "depth3"):
+            assert plan["nd_depth"] >= 1 and plan["levels"] < plan["tile_columns"]  # the orbit's chain is cut into shorter ones
+        assert plan["inverse_accumulators"] == (0 if variant == "depth2_backward_by_levels" else 1)
         h.sweep_once(1e3)
         S, rhs = h.reduced_system()
         np.testing.assert_allclose(S, ref["S"], rtol=0, atol=1e-11 * np.abs(ref["S"]).max())
