@@ -371,6 +371,7 @@ struct mpsfm_ba_handle {
   LevelPlanDev lp;
   CholItem* d_lp_items = nullptr;
   uint8_t* d_lp_live = nullptr;
+  int32_t* d_lp_col_slot = nullptr;
   int32_t *d_lp_srcs = nullptr, *d_lp_rows = nullptr, *d_lp_struct_start = nullptr, *d_lp_struct_rows = nullptr, *d_lp_back_cols = nullptr, *d_lp_asm = nullptr;
   std::vector<int32_t> nat_slot;    // variable camera in the caller's order -> slot (the accessors of S and y speak the caller's order)
   int n_user = 0;                   // 6 x variable cameras: the reduced dimension the caller sees (n also counts dummy slots)
@@ -435,7 +436,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
                   h->d_sky_first, h->d_sky_start, h->d_sky_index,
-                  h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm, h->d_lp_live};
+                  h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm, h->d_lp_live, h->d_lp_col_slot};
   for (void* p : ptrs) cached_free(p);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
   release_pinned(h->h_scal);
@@ -553,6 +554,7 @@ static int upload_plan(mpsfm_ba_handle* h, int64_t nblk) {
   if ((rc2 = dev_upload(&h->d_lp_struct_rows, PL.struct_rows))) return rc2;
   if ((rc2 = dev_upload(&h->d_lp_back_cols, PL.back_cols))) return rc2;
   if ((rc2 = dev_upload(&h->d_lp_asm, PL.asm_tiles))) return rc2;
+  if ((rc2 = dev_upload(&h->d_lp_col_slot, PL.slot_of_col))) return rc2;
   {
     std::vector<uint8_t> live((size_t)(PL.nt + 1) * (size_t)(PL.nt + 2) / 2, 0);
     for (int32_t id : PL.asm_tiles) live[(size_t)id] = 1;
@@ -562,7 +564,7 @@ static int upload_plan(mpsfm_ba_handle* h, int64_t nblk) {
   D.valid = PL.nt >= 1 && PL.nlevels >= 1; D.use_pinv = PL.use_pinv;
   D.d_items = h->d_lp_items; D.d_srcs = h->d_lp_srcs; D.d_rows = h->d_lp_rows;
   D.d_struct_start = h->d_lp_struct_start; D.d_struct_rows = h->d_lp_struct_rows; D.d_back_cols = h->d_lp_back_cols;
-  D.d_asm_tiles = h->d_lp_asm; D.d_tile_live = h->d_lp_live; D.n_asm = (int32_t)PL.asm_tiles.size(); D.nlevels = PL.nlevels;
+  D.d_asm_tiles = h->d_lp_asm; D.d_tile_live = h->d_lp_live; D.d_col_slot = PL.slot_of_col.empty() ? nullptr : h->d_lp_col_slot; D.n_asm = (int32_t)PL.asm_tiles.size(); D.nlevels = PL.nlevels;
   D.h_launch_start = PL.launch_start.data(); D.h_back_start = PL.back_start.data();
   if (h->opt.verbose >= 2)
     std::fprintf(stderr, "[mpsfm_ba] build: camera order: %s (depth %d), %d slots for %d cameras, %d tile columns in %d levels, %lld tile products, %lld inverse roles, %d blocks of S\n",
@@ -722,8 +724,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     plan_auto(graph, forced_depth, forced_depth >= -1, inv_rows < 0 ? 0 : dense_plain_max_tiles(), dense_inv_rows(), h->plan);
     lap("camera order + factorisation plan");
     h->nat_slot = h->plan.slot_of_nat;
-    h->ncv = h->plan.nslots;
-    h->n = 6 * h->ncv;
+    h->ncv = h->plan.nslots;                 // a permutation of the variable cameras
+    h->n = h->plan.n;                        // columns of the reduced system incl. the alignment padding
     h->nt = (h->n + 31) / 32;
     for (int i = 0; i < nc; ++i)
       if (slot[(size_t)i] >= 0) slot[(size_t)i] = h->plan.slot_of_nat[(size_t)slot[(size_t)i]];
@@ -1206,7 +1208,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
         for (int tj = first[(size_t)ti]; tj < ti; ++tj) pat[(size_t)ti * nt + tj] = 1;
       CholPlan& PL = h->plan;
       PL.ncv = ncv; PL.nslots = ncv; PL.n = n; PL.nd_depth = -1;
-      PL.slot_of_nat = h->nat_slot; PL.nat_of_slot = h->nat_slot;
+      PL.slot_of_nat = h->nat_slot; PL.nat_of_slot = h->nat_slot;  // identity, no padding: slot_of_col stays empty (NULL map)
       plan_from_pattern(pat, nt, nt <= dense_plain_max_tiles() && !(std::getenv("MPSFM_CHOL_INVERSE") && std::atoi(std::getenv("MPSFM_CHOL_INVERSE")) == 0),
                         dense_inv_rows(), PL);
       if (int rc2 = upload_plan(h, h->sblk_blocks)) return rc2;
@@ -1267,10 +1269,10 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_alloc(&h->d_camtab, ncs * kCamRec))) return rc;
   if ((rc = dev_alloc(&h->d_camtab2, ncs * kCamRec))) return rc;
   h->sblk_count = h->sblk_blocks * 36;
-  h->red_count = h->sblk_count + 3 * (int64_t)h->n + SC_COUNT;
+  h->red_count = h->sblk_count + 3 * (int64_t)h->n_user + SC_COUNT;
   if ((rc = dev_alloc(&h->d_red, (size_t)h->red_count))) return rc;
-  h->d_Sblk = h->d_red; h->d_gc = h->d_red + h->sblk_count; h->d_wv = h->d_gc + h->n; h->d_diagU = h->d_wv + h->n;
-  h->d_redsc = h->d_diagU + h->n;
+  h->d_Sblk = h->d_red; h->d_gc = h->d_red + h->sblk_count; h->d_wv = h->d_gc + h->n_user; h->d_diagU = h->d_wv + h->n_user;
+  h->d_redsc = h->d_diagU + h->n_user;
   if ((rc = dev_alloc(&h->d_part, (size_t)std::max(h->nchunks + h->nlong, 1) * 4))) return rc;
   if ((rc = dev_alloc(&h->d_part2, (size_t)std::max(h->nchunks + h->nlong, 1) * 8))) return rc;
   if ((rc = dev_alloc(&h->d_scal, (size_t)U_COUNT))) return rc;
@@ -1284,7 +1286,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   const size_t ntiles = (size_t)(h->nt + 1) * (h->nt + 2) / 2;
   if ((rc = dev_alloc(&h->d_A, ntiles * 1024))) return rc;
   if ((rc = dev_alloc(&h->d_dwork, dense_work_doubles(h->nt)))) return rc;
-  if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n, 1)))) return rc;
+  if ((rc = dev_alloc(&h->d_yc, (size_t)std::max(h->n_user, 1)))) return rc;
   if ((rc = dev_alloc(&h->d_fail, 1))) return rc;
   HIP_TRY(hipMemsetAsync(h->d_fail, 0, sizeof(int), h->stream));
   for (auto& e : h->ev) HIP_TRY(pooled_event(&e, true));
@@ -1303,7 +1305,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     for (auto& e : h->ov.evB) HIP_TRY(pooled_event(&e, false));
   }
   HIP_TRY(hipMemsetAsync(h->d_ps, 0, nps * 3 * sizeof(double), h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_yc, 0, (size_t)std::max(h->n, 1) * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_yc, 0, (size_t)std::max(h->n_user, 1) * sizeof(double), h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   init_tile_tables(h->stream);
   (void)st;
@@ -1386,11 +1388,11 @@ static int prepare_scales(mpsfm_ba_handle* h) {
   launch_pt_scales(h->np, h->d_pt_kv, h->d_diagV, 0, h->d_ps, s);
   launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, s);
   if (h->opt.jacobi_scaling) {
-    HIP_TRY(hipMemsetAsync(h->d_diagU, 0, sizeof(double) * (size_t)std::max(h->n, 1), s));
+    HIP_TRY(hipMemsetAsync(h->d_diagU, 0, sizeof(double) * (size_t)std::max(h->n_user, 1), s));
     HIP_TRY(hipMemsetAsync(h->d_diagV, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(h->np, 1), s));
     SweepArgs a = sweep_args(h, 1.0);
     launch_track_sweep(a, h->nchunks, true, s);
-    if (int rc = allreduce_dev(h, h->d_diagU, h->n)) return rc;
+    if (int rc = allreduce_dev(h, h->d_diagU, h->n_user)) return rc;
     launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 1, h->d_cs, s);
     launch_pt_scales(h->np, h->d_pt_kv, h->d_diagV, 1, h->d_ps, s);
     launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, s);
@@ -1424,7 +1426,7 @@ static int run_dense(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullp
     const bool listed = level && !pinv;
     AssembleArgs as{BlockSky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv}, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, h->ncv, h->n, h->nt, radius,
                     h->opt.min_lm_diagonal, h->opt.max_lm_diagonal, h->d_A, pinv, listed ? h->lp.d_asm_tiles : nullptr, listed ? h->lp.n_asm : 0,
-                    (level && pinv) ? h->d_yc : nullptr, (level && pinv) ? h->lp.d_tile_live : nullptr, ctl};
+                    h->lp.d_col_slot, h->n_user, (level && pinv) ? h->d_yc : nullptr, (level && pinv) ? h->lp.d_tile_live : nullptr, ctl};
     launch_assemble(as, s);
     launch_dense_solve(h->d_A, h->d_dwork, h->nt, h->n, h->d_yc, h->d_fail, s, &h->ov, &h->lp, ctl);
   }
@@ -1472,11 +1474,11 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   if (int rc = prepare_scales(h)) return rc;
   if (h->np > 0) HIP_TRY(hipMemcpyAsync(h->d_pts2, h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToDevice, s));
   // initial x norm: cameras through a zero-step camera update, landmarks by a reduction
-  HIP_TRY(hipMemsetAsync(h->d_yc, 0, sizeof(double) * (size_t)std::max(h->n, 1), s));
+  HIP_TRY(hipMemsetAsync(h->d_yc, 0, sizeof(double) * (size_t)std::max(h->n_user, 1), s));
   HIP_TRY(hipMemsetAsync(h->d_scal, 0, sizeof(double) * U_COUNT, s));
   double x_norm = 0.0;
   {
-    HIP_TRY(hipMemsetAsync(h->d_gc, 0, sizeof(double) * (size_t)std::max(h->n, 1), s));
+    HIP_TRY(hipMemsetAsync(h->d_gc, 0, sizeof(double) * (size_t)std::max(h->n_user, 1), s));
     launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s);
     const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (h->np + kThreads - 1) / kThreads));
     launch_pts_sqnorm(h->np, h->d_pt_kv, h->d_pts, h->d_costpart, nb, s);
@@ -1822,7 +1824,7 @@ int mpsfm_ba_get_reduced_system(mpsfm_ba_handle* h, double* S, double* rhs, int3
   std::vector<double> red((size_t)h->red_count);
   HIP_TRY(hipMemcpyAsync(red.data(), h->d_red, sizeof(double) * red.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  const double* Sb = red.data(); const double* gc = Sb + h->sblk_count; const double* wv = gc + h->n; const double* dU = wv + h->n;
+  const double* Sb = red.data(); const double* gc = Sb + h->sblk_count; const double* wv = gc + h->n_user; const double* dU = wv + h->n_user;
   const mpsfm_ba_options& o = h->opt;
   const BlockSky sky{h->sky_first.data(), h->sky_start.data(), h->sky_index.empty() ? nullptr : h->sky_index.data(), h->ncv};
   for (int R = 0; R < n; ++R)
@@ -1845,8 +1847,8 @@ int mpsfm_ba_get_dense_solution(mpsfm_ba_handle* h, double* y, int32_t n) {
   if (!h || !y) return fail(MPSFM_EINVAL, "handle or y is NULL");
   if (n != h->n_user) return fail(MPSFM_EINVAL, "n does not match the reduced dimension");
   HIP_TRY(hipSetDevice(h->device));
-  std::vector<double> ys((size_t)std::max(h->n, 1));
-  HIP_TRY(hipMemcpyAsync(ys.data(), h->d_yc, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> ys((size_t)std::max(h->n_user, 1));
+  HIP_TRY(hipMemcpyAsync(ys.data(), h->d_yc, sizeof(double) * (size_t)h->n_user, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (int i = 0; i < n; ++i) y[i] = ys[(size_t)(6 * h->nat_slot[(size_t)(i / 6)] + i % 6)];
   return 0;

@@ -8,8 +8,9 @@
 // breadth-first level structures of the camera graph, arcs in Cuthill-McKee order) turns it into independent chains that
 // advance in the same launches: C3 38 -> 17 levels, C4 188 -> 25-34, for ~20 % more tile products.
 //
-//   camera graph -> order_cameras() -> slots (dummy slots pad every non-root segment to a multiple of 16 slots = 3 tiles,
-//   so no tile straddles two segments) -> tile pattern -> symbolic factorisation, elimination tree, levels -> item tables.
+//   camera graph -> order_cameras() -> slots and their first columns (padding columns — identity rows of the system — end
+//   every non-root segment on a 32-column tile boundary, so no tile straddles two segments) -> tile pattern -> symbolic
+//   factorisation, elimination tree, levels -> item tables.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -38,8 +39,10 @@ struct CholPlan {
   int ncv = 0, nslots = 0, n = 0, nt = 0, nlevels = 0;
   int nd_depth = -1;  // -1: caller's order
   bool use_pinv = false;
-  std::vector<int32_t> slot_of_nat;  // [ncv]    variable camera (caller's order) -> slot
-  std::vector<int32_t> nat_of_slot;  // [nslots] slot -> variable camera, -1: dummy slot
+  std::vector<int32_t> slot_of_nat;  // [ncv]    variable camera (caller's order) -> slot (a permutation: nslots == ncv)
+  std::vector<int32_t> nat_of_slot;  // [nslots] slot -> variable camera
+  std::vector<int32_t> col_of_slot;  // [nslots] first of the slot's six columns in the reduced system (n columns in all)
+  std::vector<int32_t> slot_of_col;  // [n]      slot * 8 + coordinate of every column, -1: padding (identity row)
   std::vector<int32_t> struct_start, struct_rows;  // per tile column j: the rows i > j with L(i,j) != 0, ascending, the rhs row nt last
   std::vector<int32_t> parent, level;              // tile elimination tree
   std::vector<CholItem> items;
@@ -55,8 +58,10 @@ struct CholPlan {
 // tables = false: symbolic factorisation, levels and the cost estimate only (plan_auto compares candidates that way)
 void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, int inv_rows, CholPlan& P, bool tables = true);
 // slot order from the camera graph.  depth < 0: caller's order; depth >= 0: nested dissection of that depth (0: components + RCM)
-void order_cameras(const CamGraph& g, int depth, std::vector<int32_t>& slot_of_nat, int& nslots);
-void tile_pattern(const CamGraph& g, const std::vector<int32_t>& slot_of_nat, int nslots, std::vector<uint8_t>& pat, int& nt);
+// move_up: a segment that exceeds a whole number of tiles by at most this many cameras hands them to its parent's separator
+void order_cameras(const CamGraph& g, int depth, int move_up, std::vector<int32_t>& slot_of_nat, std::vector<int32_t>& col_of_slot, int& n_cols);
+void tile_pattern(const CamGraph& g, const std::vector<int32_t>& slot_of_nat, const std::vector<int32_t>& col_of_slot, int n_cols,
+                  std::vector<uint8_t>& pat, int& nt);
 // tries the caller's order and dissection depths 0 .. max, keeps the cheapest by the launch-cost model (forced_depth >= -1: that one)
 void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_tiles, int inv_rows, CholPlan& P);
 

@@ -12,8 +12,7 @@
 namespace mpsfm {
 namespace {
 
-constexpr int kSegAlign = 16;    // slots per alignment unit: 16 cameras x 6 columns = 3 tiles
-constexpr int kMoveUpMax = 4;    // a segment with this many cameras beyond a multiple of 16 hands them to its parent instead of padding
+constexpr int kTileCols = 32;    // every segment but the last ends on a tile boundary (padding columns)
 constexpr int kMinLeaf = 32;     // no dissection below this many cameras
 constexpr int kMinBfsLevels = 5;
 constexpr double kMaxPlanProducts = 3.0e6;  // tile products beyond which no item table is built (tens of MB of tables, seconds to build)
@@ -150,37 +149,42 @@ int dissect(Sub& S, std::vector<Seg>& tree, const std::vector<int>& nodes, int d
   return me;
 }
 
-// Post-order flattening.  Every segment but the last one is made a multiple of kSegAlign slots: a few surplus cameras move
-// up into the parent's separator (still a separator), otherwise dummy slots (-1) pad it.
-void flatten(const std::vector<Seg>& tree, int node, bool is_root, std::vector<int>& out, std::vector<int>& up) {
+// Post-order flattening.  kSegEnd after every segment but the last: the next camera starts on a tile boundary (padding
+// columns in between).  A segment that exceeds a whole number of tiles by a few cameras hands them to its parent instead
+// (a separator stays one when it grows), so that its chain is a tile shorter.
+constexpr int kSegEnd = -1;
+void flatten(const std::vector<Seg>& tree, int node, bool is_root, int move_up, std::vector<int>& out, std::vector<int>& up) {
   std::vector<int> cams;
   for (int c : tree[(size_t)node].child) {
     std::vector<int> moved;
-    flatten(tree, c, false, out, moved);
+    flatten(tree, c, false, move_up, out, moved);
     cams.insert(cams.end(), moved.begin(), moved.end());
   }
   const std::vector<int>& own = tree[(size_t)node].cams;
-  if (!is_root && own.empty()) { up = cams; return; }  // nothing of its own: whatever moved up keeps moving
+  if (!is_root && own.empty()) { up = cams; return; }  // independent parts under an empty separator: what moved up keeps moving
   cams.insert(cams.end(), own.begin(), own.end());
+  if (cams.empty()) return;
   if (!is_root) {
-    const int r = (int)cams.size() % kSegAlign;
-    if (r > 0 && r <= kMoveUpMax && (int)cams.size() > kSegAlign) {
-      up.assign(cams.end() - r, cams.end());
-      cams.resize(cams.size() - (size_t)r);
-    } else if (r > 0) {
-      cams.insert(cams.end(), (size_t)(kSegAlign - r), -1);
+    const int k = (int)cams.size();
+    const int whole = (6 * k) / kTileCols * kTileCols / 6;  // cameras that fit the whole tiles of the segment
+    const int over = k - whole;
+    if (over > 0 && over <= move_up && whole > 0 && (6 * k) % kTileCols != 0) {
+      up.assign(cams.end() - over, cams.end());
+      cams.resize((size_t)whole);
     }
   }
   out.insert(out.end(), cams.begin(), cams.end());
+  if (!is_root) out.push_back(kSegEnd);
 }
 
 }  // namespace
 
-void order_cameras(const CamGraph& g, int depth, std::vector<int32_t>& slot_of_nat, int& nslots) {
+void order_cameras(const CamGraph& g, int depth, int move_up, std::vector<int32_t>& slot_of_nat, std::vector<int32_t>& col_of_slot, int& n_cols) {
   slot_of_nat.assign((size_t)g.n, -1);
+  col_of_slot.assign((size_t)g.n, 0);
   if (depth < 0 || g.n == 0) {
-    for (int i = 0; i < g.n; ++i) slot_of_nat[(size_t)i] = i;
-    nslots = g.n;
+    for (int i = 0; i < g.n; ++i) { slot_of_nat[(size_t)i] = i; col_of_slot[(size_t)i] = 6 * i; }
+    n_cols = 6 * g.n;
     return;
   }
   Sub S(g);
@@ -189,17 +193,25 @@ void order_cameras(const CamGraph& g, int depth, std::vector<int32_t>& slot_of_n
   for (int i = 0; i < g.n; ++i) all[(size_t)i] = i;
   dissect(S, tree, all, depth);
   std::vector<int> out, up;
-  flatten(tree, 0, true, out, up);
-  nslots = (int)out.size();
-  for (int s = 0; s < nslots; ++s) if (out[(size_t)s] >= 0) slot_of_nat[(size_t)out[(size_t)s]] = s;
+  flatten(tree, 0, true, move_up, out, up);
+  while (!out.empty() && out.back() == kSegEnd) out.pop_back();  // nothing follows the last segment
+  int slot = 0, col = 0;
+  for (int v : out) {
+    if (v == kSegEnd) { col = (col + kTileCols - 1) / kTileCols * kTileCols; continue; }
+    slot_of_nat[(size_t)v] = slot;
+    col_of_slot[(size_t)slot] = col;
+    ++slot; col += 6;
+  }
+  n_cols = col;
 }
 
-void tile_pattern(const CamGraph& g, const std::vector<int32_t>& slot_of_nat, int nslots, std::vector<uint8_t>& pat, int& nt) {
-  const int n = 6 * nslots;
-  nt = (n + 31) / 32;
+void tile_pattern(const CamGraph& g, const std::vector<int32_t>& slot_of_nat, const std::vector<int32_t>& col_of_slot, int n_cols,
+                  std::vector<uint8_t>& pat, int& nt) {
+  nt = (n_cols + 31) / 32;
   pat.assign((size_t)nt * (size_t)nt, 0);
   auto mark = [&](int sa, int sb) {
-    const int a0 = (6 * sa) / 32, a1 = (6 * sa + 5) / 32, b0 = (6 * sb) / 32, b1 = (6 * sb + 5) / 32;
+    const int ca = col_of_slot[(size_t)sa], cb = col_of_slot[(size_t)sb];
+    const int a0 = ca / 32, a1 = (ca + 5) / 32, b0 = cb / 32, b1 = (cb + 5) / 32;
     for (int a = a0; a <= a1; ++a)
       for (int b = b0; b <= b1; ++b) { if (a > b) pat[(size_t)a * nt + b] = 1; else if (b > a) pat[(size_t)b * nt + a] = 1; }
   };
@@ -362,19 +374,25 @@ void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_ti
   std::vector<uint8_t> best_pat;
   for (int d = -1; d <= (forced ? -1 : dmax); ++d) {
     const int depth = forced ? forced_depth : d;
-    CholPlan P;
-    P.ncv = g.n; P.nd_depth = depth;
-    order_cameras(g, depth, P.slot_of_nat, P.nslots);
-    P.n = 6 * P.nslots;
-    std::vector<uint8_t> pat;
-    int nt = 0;
-    tile_pattern(g, P.slot_of_nat, P.nslots, pat, nt);
-    plan_from_pattern(pat, nt, nt <= pinv_max_tiles, inv_rows, P, /*tables=*/false);
-    if (!have || P.est_us < best.est_us - 1e-9) { best = std::move(P); best_pat = std::move(pat); have = true; }
+    for (int move_up : {0, 2, 4}) {
+      if (depth < 1 && move_up > 0) break;  // nothing to move without separators
+      CholPlan P;
+      P.ncv = g.n; P.nd_depth = depth;
+      P.nslots = g.n;
+      order_cameras(g, depth, move_up, P.slot_of_nat, P.col_of_slot, P.n);
+      std::vector<uint8_t> pat;
+      int nt = 0;
+      tile_pattern(g, P.slot_of_nat, P.col_of_slot, P.n, pat, nt);
+      plan_from_pattern(pat, nt, nt <= pinv_max_tiles, inv_rows, P, /*tables=*/false);
+      if (!have || P.est_us < best.est_us - 1e-9) { best = std::move(P); best_pat = std::move(pat); have = true; }
+    }
   }
   plan_from_pattern(best_pat, best.nt, best.nt <= pinv_max_tiles, inv_rows, best, /*tables=*/true);
   best.nat_of_slot.assign((size_t)best.nslots, -1);
   for (int i = 0; i < g.n; ++i) best.nat_of_slot[(size_t)best.slot_of_nat[(size_t)i]] = i;
+  best.slot_of_col.assign((size_t)best.n, -1);
+  for (int sl = 0; sl < best.nslots; ++sl)
+    for (int a = 0; a < 6; ++a) best.slot_of_col[(size_t)best.col_of_slot[(size_t)sl] + a] = sl * 8 + a;
 }
 
 }  // namespace mpsfm
@@ -399,7 +417,7 @@ mpsfm_plan_handle* mpsfm_debug_plan_create(const uint8_t* adj, int32_t n, int32_
 void mpsfm_debug_plan_destroy(mpsfm_plan_handle* h) { delete h; }
 // what: 0 header {ncv, nslots, n, nt, nlevels, nd_depth, use_pinv, n_items, products, roles}; 1 slot_of_nat; 2 struct_start; 3 struct_rows;
 // 4 parent; 5 level; 6 items (4 int32 each: type | ti << 16, tk | nsrc << 16, src, aux); 7 launch_start; 8 srcs; 9 rows; 10 asm_tiles;
-// 11 back_cols; 12 back_start.  Returns the length; copies min(length, cap) entries.
+// 11 back_cols; 12 back_start; 13 col_of_slot.  Returns the length; copies min(length, cap) entries.
 int64_t mpsfm_debug_plan_get(const mpsfm_plan_handle* h, int32_t what, int32_t* out, int64_t cap) {
   if (!h) return -1;
   const mpsfm::CholPlan& P = h->P;
@@ -424,6 +442,7 @@ int64_t mpsfm_debug_plan_get(const mpsfm_plan_handle* h, int32_t what, int32_t* 
     case 10: v = &P.asm_tiles; break;
     case 11: v = &P.back_cols; break;
     case 12: v = &P.back_start; break;
+    case 13: v = &P.col_of_slot; break;
     default: return -1;
   }
   if (out) std::memcpy(out, v->data(), sizeof(int32_t) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));

@@ -236,6 +236,13 @@ __host__ __device__ inline bool sky_has(const BlockSky& k, int64_t i, int64_t j)
 __host__ __device__ inline int64_t sky_block(const BlockSky& k, int64_t i, int64_t j) {
   return k.index ? (int64_t)k.index[j * k.ns + i] : k.start[j] + (i - k.first[j]);
 }
+// position of system column g in the slot-indexed vectors, -1 for a padding column or beyond the system
+__host__ __device__ inline int vec_index(const int32_t* col_slot, int g, int n) {
+  if (g >= n) return -1;
+  if (!col_slot) return g;
+  const int cs = col_slot[g];
+  return cs < 0 ? -1 : (cs >> 3) * 6 + (cs & 7);
+}
 // packed index of lower-triangle tile (ti >= tj)
 __host__ __device__ inline int64_t lt_tile(int64_t ti, int64_t tj) { return ti * (ti + 1) / 2 + tj; }
 
@@ -320,6 +327,7 @@ struct LevelPlanDev {
   const int32_t* d_struct_start = nullptr;
   const int32_t* d_struct_rows = nullptr;
   const int32_t* d_back_cols = nullptr;
+  const int32_t* d_col_slot = nullptr;   // AssembleArgs::col_slot
   const int32_t* d_asm_tiles = nullptr;
   const uint8_t* d_tile_live = nullptr;  // [(nt+1)(nt+2)/2] 1 for the tiles in d_asm_tiles
   int32_t n_asm = 0, nlevels = 0;
@@ -336,7 +344,10 @@ struct AssembleArgs {
   double* Pinv;  // accumulators of the inverse propagation (same tile indexing as A), zeroed here; may be NULL
   const int32_t* tile_list;  // packed ids of the tiles to assemble (one workgroup each), NULL: all (nt+1)(nt+2)/2
   int32_t n_list;
-  double* y;                 // solution vector, zeroed here when the back substitution accumulates into it (else NULL)
+  const int32_t* col_slot;   // [n] slot * 8 + coordinate of every column of the system, -1: padding column (identity row);
+                             // NULL: column c belongs to slot c / 6 (no padding).  Vectors (gc, wv, diagU, y) are indexed by slot.
+  int32_t n_vec;             // 6 x slots: length of those vectors
+  double* y;                 // solution vector (slot-indexed), zeroed here when the back substitution accumulates into it (else NULL)
   const uint8_t* live;       // all tiles launched (inverse accumulators to zero): per packed id, 0 = the factorisation never
                              // reads this tile of A, skip the gather; NULL: every tile is assembled
   const LmCtl* ctl;  // as in SweepArgs

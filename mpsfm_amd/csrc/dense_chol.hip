@@ -32,27 +32,28 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
   if (P.Pinv && ti < P.nt && tj < ti)
     for (int e = threadIdx.x; e < kTileElems; e += 256) P.Pinv[id * kTileElems + e] = 0.0;
   if (P.y && blockIdx.x == 0)  // the solution vector is accumulated with atomics (k_inv_y): start from zero
-    for (int e = threadIdx.x; e < n; e += 256) P.y[e] = 0.0;
+    for (int e = threadIdx.x; e < P.n_vec; e += 256) P.y[e] = 0.0;
   if (P.live && !P.live[id]) return;  // outside the symbolic factor: nobody reads this tile
   for (int e = threadIdx.x; e < kTileElems; e += 256) {
     const int r = e >> 5, c = e & 31;
     const int C = tj * kTile + c;
     double v = 0.0;
     if (ti == P.nt) {
-      if (tj < P.nt && r == 0 && C < n) v = P.wv[C] - P.gc[C];
+      const int ic = vec_index(P.col_slot, C, n);
+      if (tj < P.nt && r == 0 && ic >= 0) v = P.wv[ic] - P.gc[ic];
     } else {
       const int R = ti * kTile + r;
-      if (R >= n || C >= n) {
-        v = (R == C) ? 1.0 : 0.0;
+      const int ir = vec_index(P.col_slot, R, n), ic = vec_index(P.col_slot, C, n);
+      if (ir < 0 || ic < 0) {
+        v = (R == C) ? 1.0 : 0.0;  // padding columns (tile alignment of the dissection's parts, tail of the last tile): identity
       } else {
-        const int br = R / 6, a = R - br * 6, bc = C / 6, b = C - bc * 6;
+        const int br = ir / 6, a = ir - br * 6, bc = ic / 6, b = ic - bc * 6;
         const int lo = br < bc ? br : bc, hi = br < bc ? bc : br;
         if (!sky_has(P.sky, lo, hi)) v = 0.0;  // no landmark shared by the two cameras: structurally zero
         else if (br < bc) v = P.Sblk[sky_block(P.sky, br, bc) * 36 + a * 6 + b];
         else if (br > bc) v = P.Sblk[sky_block(P.sky, bc, br) * 36 + b * 6 + a];
         else v = P.Sblk[sky_block(P.sky, br, br) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
-        // an alignment slot (no camera: not even its diagonal block exists) is an identity row, whatever the damping options
-        if (R == C) v += sky_has(P.sky, br, br) ? fmin(fmax(P.diagU[R], P.min_diag), P.max_diag) / lm_radius : 1.0;
+        if (R == C) v += fmin(fmax(P.diagU[ir], P.min_diag), P.max_diag) / lm_radius;
       }
     }
     T[e] = v;
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_level(LevelArgs G) {
 // per tile column j of the level: v = z_j - sum_{i in struct(j)} L(i,j)^T y_i (all those i are ancestors: final), then
 // y_j = L(j,j)^-T v with the stored inverse.  z_j is row 0 of the right-hand-side tile (nt, j).
 __global__ __launch_bounds__(256) void k_back_level(const double* A, const double* LinvT, const int32_t* cols, const int32_t* struct_start,
-                                                    const int32_t* struct_rows, int nt, int n, double* ybuf, double* y, const LmCtl* ctl) {
+                                                    const int32_t* struct_rows, int nt, int n, double* ybuf, double* y, const int32_t* col_slot, const LmCtl* ctl) {
   __shared__ double s_part[8][kTile];
   __shared__ double s_v[kTile];
   if (lm_over(ctl)) return;
@@ -639,7 +640,8 @@ __global__ __launch_bounds__(256) void k_back_level(const double* A, const doubl
 #pragma unroll
     for (int q = 0; q < kTile; ++q) yr = __builtin_fma(Li[q], s_v[q], yr);
     ybuf[(size_t)j * kTile + c] = yr;
-    if (j * kTile + c < n) y[j * kTile + c] = yr;
+    const int iy = vec_index(col_slot, j * kTile + c, n);
+    if (iy >= 0) y[iy] = yr;
   }
 }
 
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(256) void k_z_init(const double* A, int nt, double*
 }
 
 __global__ __launch_bounds__(256) void k_backsub_group(const double* A, const double* LinvT, int nt, int n, int t0, int t1,
-                                                      double* zbuf, double* y) {
+                                                      double* zbuf, double* y, const int32_t* col_slot) {
   __shared__ double s_tiles[(kBsG + kBsG * (kBsG - 1) / 2) * kTileElems];  // LinvT of the group, then L[tj][c], c<tj in group
   __shared__ double s_z[kBsG * kTile];
   __shared__ double s_y[kBsG * kTile];
@@ -738,7 +740,8 @@ __global__ __launch_bounds__(256) void k_backsub_group(const double* A, const do
   }
   if (w == 0 && tid < G * kTile) {
     const int gidx = t0 * kTile + tid;
-    if (gidx < n) y[gidx] = s_y[tid];
+    const int iy = vec_index(col_slot, gidx, n);
+    if (iy >= 0) y[iy] = s_y[tid];
   }
 }
 
@@ -747,7 +750,8 @@ __global__ __launch_bounds__(256) void k_backsub_group(const double* A, const do
 // are cut into kInvSplit workgroups (i = k+1+s mod kInvSplit); every workgroup first forms the w_i it needs itself (a
 // 32 x 32 product each — cheaper than a launch of its own for them), split 0 also w_k.  y starts from zero (k_assemble).
 constexpr int kInvSplit = 4;
-__global__ __launch_bounds__(256) void k_inv_y(const double* A, const double* LinvT, const double* Pinv, int nt, int n, double* y, const LmCtl* ctl) {
+__global__ __launch_bounds__(256) void k_inv_y(const double* A, const double* LinvT, const double* Pinv, int nt, int n, double* y,
+                                               const int32_t* col_slot, const LmCtl* ctl) {
   __shared__ double s_w[(kPlainMaxTiles / kInvSplit + 2) * kTile];
   __shared__ double s_part[8][kTile];
   if (lm_over(ctl)) return;
@@ -781,7 +785,8 @@ __global__ __launch_bounds__(256) void k_inv_y(const double* A, const double* Li
 #pragma unroll
     for (int q = 0; q < 8; ++q) v += s_part[q][c];
     const int g = k * kTile + c;
-    if (g < n) atomicAdd(&y[g], (own ? s_w[c] : 0.0) - v);
+    const int iy = vec_index(col_slot, g, n);
+    if (iy >= 0) atomicAdd(&y[iy], (own ? s_w[c] : 0.0) - v);
   }
 }
 
@@ -827,7 +832,6 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   if (nt <= 0) return;
   double* LinvT = work;
   double* zbuf = work + (size_t)nt * kTileElems;
-  double* wbuf = zbuf + (size_t)nt * kTile;
   if (dense_level(ov, lp)) {
     double* Pinv = dense_pinv(work, nt, ov, lp);
     LevelArgs G{A, LinvT, Pinv, nullptr, lp->d_srcs, lp->d_rows, fail, nt, g_dbg_flags, ctl};
@@ -838,14 +842,14 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
       hipLaunchKernelGGL(k_chol_level, dim3((unsigned)grid), dim3(kStepThreads), 0, s, G);
     }
     if (Pinv) {
-      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, A, LinvT, Pinv, nt, n, y, ctl);
+      hipLaunchKernelGGL(k_inv_y, dim3(nt, kInvSplit), dim3(256), 0, s, A, LinvT, Pinv, nt, n, y, lp->d_col_slot, ctl);
       return;
     }
     for (int l = 0; l < lp->nlevels; ++l) {
       const int grid = lp->h_back_start[l + 1] - lp->h_back_start[l];
       if (grid <= 0) continue;
       hipLaunchKernelGGL(k_back_level, dim3((unsigned)grid), dim3(256), 0, s, A, LinvT, lp->d_back_cols + lp->h_back_start[l], lp->d_struct_start,
-                         lp->d_struct_rows, nt, n, zbuf, y, ctl);
+                         lp->d_struct_rows, nt, n, zbuf, y, lp->d_col_slot, ctl);
     }
     return;
   }
@@ -898,7 +902,7 @@ void launch_dense_solve(double* A, double* work, int nt, int n, double* y, int* 
   hipLaunchKernelGGL(k_z_init, dim3((nt * kTile + 255) / 256), dim3(256), 0, s, A, nt, zbuf);
   for (int t1 = nt; t1 > 0; t1 -= kBsG) {
     const int t0 = t1 - kBsG > 0 ? t1 - kBsG : 0;
-    hipLaunchKernelGGL(k_backsub_group, dim3(t0 > 0 ? t0 : 1), dim3(256), 0, s, A, LinvT, nt, n, t0, t1, zbuf, y);
+    hipLaunchKernelGGL(k_backsub_group, dim3(t0 > 0 ? t0 : 1), dim3(256), 0, s, A, LinvT, nt, n, t0, t1, zbuf, y, lp ? lp->d_col_slot : nullptr);
   }
 }
 

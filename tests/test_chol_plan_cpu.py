@@ -25,7 +25,7 @@ def _plan(adj, depth=-2, pinv_max_tiles=64, inv_rows=2):
     assert h
     out = {}
     names = ["header", "slot_of_nat", "struct_start", "struct_rows", "parent", "level", "items", "launch_start", "srcs", "rows",
-             "asm_tiles", "back_cols", "back_start"]
+             "asm_tiles", "back_cols", "back_start", "col_of_slot"]
     for what, name in enumerate(names):
         n = L.mpsfm_debug_plan_get(h, what, None, 0)
         buf = np.zeros(max(n, 1), np.int32)
@@ -55,24 +55,26 @@ def ring_graph(n, reach, extra=0, seed=0):
 
 
 def reduced_system(adj, P, seed):
-    """SPD matrix with the block pattern of the graph in SLOT order (dummy slots: a small positive diagonal), and a rhs."""
+    """SPD matrix with the block pattern of the graph, every camera's 6 x 6 blocks at the columns the plan gives its slot
+    (padding columns between segments: identity rows), and a rhs."""
     rng = np.random.default_rng(seed)
     ncv, ns, n = P["ncv"], P["nslots"], P["n"]
-    slot = P["slot_of_nat"]
+    slot = P["col_of_slot"][P["slot_of_nat"]] // 6 if False else None
+    col = P["col_of_slot"][P["slot_of_nat"]]  # first column of every camera (caller's order)
     S = np.zeros((n, n))
     for i in range(ncv):
         for j in range(i, ncv):
             if i == j or adj[i, j]:
                 B = rng.standard_normal((6, 6)) * (1.0 if i == j else 0.3)
-                a, b = 6 * slot[i], 6 * slot[j]
+                a, b = int(col[i]), int(col[j])
                 S[a:a + 6, b:b + 6] += B
                 if i != j:
                     S[b:b + 6, a:a + 6] += B.T
     S = 0.5 * (S + S.T)
     real = np.zeros(n, bool)
     for i in range(ncv):
-        real[6 * slot[i]:6 * slot[i] + 6] = True
-    S[np.diag_indices(n)] = np.where(real, np.abs(S).sum(1) + 1.0, 1e-10)
+        real[col[i]:col[i] + 6] = True
+    S[np.diag_indices(n)] = np.where(real, np.abs(S).sum(1) + 1.0, 1.0)
     rhs = np.where(real, rng.standard_normal(n), 0.0)
     return S, rhs
 
@@ -189,9 +191,11 @@ def interpret(P, S, rhs, rng):
 def test_plan_solves_the_reduced_system(n, reach, extra, depth, pinv):
     adj = ring_graph(n, reach, extra, seed=n)
     P = _plan(adj, depth=depth, pinv_max_tiles=64 if pinv else 0)
-    assert P["ncv"] == n and P["nslots"] >= n and P["n"] == 6 * P["nslots"]
+    assert P["ncv"] == n and P["nslots"] == n and P["n"] >= 6 * n
     slot = P["slot_of_nat"]
-    assert len(set(slot.tolist())) == n and slot.min() >= 0 and slot.max() < P["nslots"]
+    assert sorted(slot.tolist()) == list(range(n))  # a permutation
+    c = np.sort(P["col_of_slot"])
+    assert c[0] == 0 and (np.diff(c) >= 6).all() and c[-1] + 6 == P["n"]  # six columns each, no overlap
     assert P["use_pinv"] == int(pinv and P["nt"] <= 64)
     S, rhs = reduced_system(adj, P, seed=1)
     y = interpret(P, S, rhs, np.random.default_rng(5))
