@@ -208,8 +208,8 @@ int mpsfm_ba_get_dense_solution(mpsfm_ba_handle* h, double* y, int32_t n);
 /* Factor + solve only, on the last assembled system (prices the MFMA dense solve). */
 int mpsfm_ba_dense_solve_once(mpsfm_ba_handle* h, float* elapsed_ms);
 /* How the handle factors the reduced camera system (what Ceres' fill-reducing ordering and sparse
- * Cholesky do behind bundle_adjustment.py:288).  info[0..9] = camera slots incl. alignment dummies,
- * 32-column tile columns, levels of the tile elimination tree (= factorisation launches),
+ * Cholesky do behind bundle_adjustment.py:288).  info[0..9] = camera slots (= variable cameras),
+ * 32-column tile columns of the system incl. the alignment padding, levels of the tile elimination tree (= factorisation launches),
  * nested-dissection depth (-1: caller's camera order), 1 if the back substitution uses the
  * inverse accumulators, work items, tile products, inverse roles, 6x6 blocks of S stored,
  * back-substitution launches. */

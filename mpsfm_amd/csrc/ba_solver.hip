@@ -374,7 +374,8 @@ struct mpsfm_ba_handle {
   int32_t* d_lp_col_slot = nullptr;
   int32_t *d_lp_srcs = nullptr, *d_lp_rows = nullptr, *d_lp_struct_start = nullptr, *d_lp_struct_rows = nullptr, *d_lp_back_cols = nullptr, *d_lp_asm = nullptr;
   std::vector<int32_t> nat_slot;    // variable camera in the caller's order -> slot (the accessors of S and y speak the caller's order)
-  int n_user = 0;                   // 6 x variable cameras: the reduced dimension the caller sees (n also counts dummy slots)
+  int n_user = 0;                   // 6 x variable cameras: the reduced dimension the caller sees and the length of the slot-indexed vectors (n counts the
+                                    // system's columns incl. the alignment padding)
   bool own_stream = false;
   mpsfm_ba_options opt{};
   LossParams loss{};
