@@ -368,8 +368,8 @@ void plan_from_pattern(const std::vector<uint8_t>& pat, int nt, bool use_pinv, i
 
 void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_tiles, int inv_rows, CholPlan& best) {
   int dmax = -1;
-  for (int s = g.n; s >= kMinLeaf; s /= 2) ++dmax;  // parts of at least kMinLeaf cameras are worth cutting again
-  dmax = std::min(dmax, 5);
+  for (int s = g.n; s >= kMinLeaf / 2; s /= 2) ++dmax;  // candidate depths down to parts of ~kMinLeaf / 2 cameras (dissect() itself
+  dmax = std::min(dmax, 6);                             // stops at kMinLeaf); the cost model decides (C3: depth 3, 14 levels)
   bool have = false;
   std::vector<uint8_t> best_pat;
   for (int d = -1; d <= (forced ? -1 : dmax); ++d) {
