@@ -6,7 +6,7 @@
 // load, one 32-column factorisation in a wave), so what counts is the length of the dependent chain.  In the caller's
 // camera order an orbit / video sequence is a band: one chain of nt steps.  A nested-dissection order (separators from
 // breadth-first level structures of the camera graph, arcs in Cuthill-McKee order) turns it into independent chains that
-// advance in the same launches: C3 38 -> 17 levels, C4 188 -> 25-34, for ~20 % more tile products.
+// advance in the same launches: C3 38 -> 14 levels, C4 188 -> 20, for ~20 % more tile products.
 //
 //   camera graph -> order_cameras() -> slots and their first columns (padding columns — identity rows of the system — end
 //   every non-root segment on a 32-column tile boundary, so no tile straddles two segments) -> tile pattern -> symbolic
