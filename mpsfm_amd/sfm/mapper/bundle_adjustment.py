@@ -19,6 +19,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from ...baseclass import BaseClass
+from ...utils.ids import unique_ids
 from ...problem import LOSS_BY_NAME, LOSS_CAUCHY, LOSS_SOFT_L1, LOSS_TRIVIAL, BAProblem
 from ..scene.prior_gather import F_GROSS, F_POSITIVE, F_SCALE, F_VALID, gather_bundle
 from ..scene.priorutils import fit_robust_gaussian_mad
@@ -158,7 +159,7 @@ class Optimizer(BaseClass):
             pids_l.append(np.asarray(image.point3D_ids(p2d), dtype=np.uint64))
             xy_l.append(np.asarray(image.keypoint_coordinates(p2d), dtype=np.float64).reshape(-1, 2))
         if pids_l:
-            uniq, inv, counts = np.unique(np.concatenate(pids_l), return_inverse=True, return_counts=True)
+            uniq, inv, counts = unique_ids(np.concatenate(pids_l), return_counts=True)
             obs_cam, obs_pt, obs_xy = [np.concatenate(cams_l)], [inv.astype(np.int32)], list(xy_l)
         else:
             uniq, counts = np.zeros(0, np.uint64), np.zeros(0, np.int64)

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from ...utils.ids import unique_ids
+
 F_VALID, F_POSITIVE, F_SCALE, F_GROSS = 1, 2, 4, 8
 
 
@@ -42,7 +44,7 @@ def gather_bundle(rec, imids, depth_type="update"):
     if not images:
         return None
     pid = np.concatenate(o_pid)
-    point_ids, obs_pt = np.unique(pid, return_inverse=True)
+    point_ids, obs_pt = unique_ids(pid)
     return dict(images=images, depth_maps=maps, valid_maps=valids, sx=np.array(sx), sy=np.array(sy), cam_quat=np.array(quat).reshape(-1, 4),
                 cam_t=np.array(trans).reshape(-1, 3), obs_img=np.concatenate(o_img), obs_xy=np.concatenate(o_xy), obs_var=np.concatenate(o_var),
                 obs_pid=pid, obs_pt=obs_pt.astype(np.int32), obs_p2d=np.concatenate(o_p2d), point_ids=point_ids)
