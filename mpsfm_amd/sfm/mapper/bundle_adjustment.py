@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from ...baseclass import BaseClass
-from ...utils.ids import unique_ids
+from ...utils.ids import index_in_sorted, unique_ids
 from ...problem import LOSS_BY_NAME, LOSS_CAUCHY, LOSS_SOFT_L1, LOSS_TRIVIAL, BAProblem
 from ..scene.prior_gather import F_GROSS, F_POSITIVE, F_SCALE, F_VALID, gather_bundle
 from ..scene.priorutils import fit_robust_gaussian_mad
@@ -255,7 +255,7 @@ class Optimizer(BaseClass):
                     self.log("No valid points for depth regularizing", level=1)
             cam_idx = np.array([cam_of[i] for i in g["images"]], np.int32)
             dobs_cam = cam_idx[g["obs_img"][mask]]
-            dobs_pt = np.searchsorted(self._sorted_point_ids, g["obs_pid"][mask]).astype(np.int32)
+            dobs_pt = index_in_sorted(self._sorted_point_ids, g["obs_pid"][mask]).astype(np.int32)
             dobs_d, dobs_m, dobs_a = out["depth"][mask], out["magnitude"][mask], out["param"][mask]
 
         n_cams = len(image_ids)
