@@ -1,4 +1,6 @@
-"""Phase timeline of k_chol_step's diagonal workgroup (wall_clock64 stamps, 10 ns units)."""
+"""Phase timeline of the diagonal workgroup of every tile column in k_chol_level (wall_clock64 stamps, 10 ns units).
+Set MPSFM_CHOL_ND=-1 for one column per launch (the caller's camera order): then consecutive columns are consecutive launches
+and the "gap" column is the launch boundary."""
 import sys, ctypes as C, numpy as np
 sys.path.insert(0,'.')
 import torch
@@ -8,7 +10,7 @@ prob,_=make_config(sys.argv[1] if len(sys.argv) > 1 else "C3")
 h=capi.BAHandle(prob)
 h.sweep_once(1e4)
 L=capi.lib()
-nt=(h.reduced_dim+31)//32
+nt=h.dense_plan()["tile_columns"]
 buf=torch.zeros((nt+1)*2*8, dtype=torch.int64, device="cuda")
 L.mpsfm_debug_set_chol_trace.argtypes=[C.c_void_p]
 for _ in range(3): h.dense_solve_once()
