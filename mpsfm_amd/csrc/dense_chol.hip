@@ -16,6 +16,63 @@ constexpr int kTile = 32;
 constexpr int kTileElems = kTile * kTile;
 constexpr int kPlainMaxTiles = 64;  // up to this many tile columns: one outer panel, inverse propagation instead of back substitution
 
+// four elements (rows r0 + k * rstep, k < 4, column c) of tile (ti, tj) of the damped reduced system [S + D / radius | rhs row];
+// tile row nt carries the right-hand side in its row 0.  Branch-free per element, so that the three dependent loads
+// (column -> slot, slot pair -> block, block -> value) of the four elements overlap.
+__device__ __forceinline__ void assemble_quad(const AssembleArgs& P, double lm_radius, int ti, int tj, int r0, int rstep, int c, double out[4]) {
+  const int n = P.n;
+  const int C = tj * kTile + c;
+  const int ic = vec_index(P.col_slot, C, n);
+  if (ti == P.nt) {
+    const double rhs = (tj < P.nt && ic >= 0) ? P.wv[ic] - P.gc[ic] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (r0 + k * rstep == 0) ? rhs : 0.0;
+    return;
+  }
+  const int icv = ic >= 0 ? ic : 0;
+  const int bc = icv / 6, b = icv - bc * 6;
+  int ir[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ir[k] = vec_index(P.col_slot, ti * kTile + r0 + k * rstep, n);
+  int64_t off[4];
+  bool has[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool real = ir[k] >= 0 && ic >= 0;
+    const int irv = ir[k] >= 0 ? ir[k] : 0;
+    const int br = irv / 6, a = irv - br * 6;
+    const int lo = br < bc ? br : bc, hi = br < bc ? bc : br;
+    int64_t blk;
+    if (P.sky.index) blk = P.sky.index[(int64_t)hi * P.sky.ns + lo];
+    else blk = lo >= P.sky.first[hi] ? P.sky.start[hi] + (lo - P.sky.first[hi]) : -1;
+    has[k] = real && blk >= 0;  // no landmark shared by the two cameras: structurally zero
+    // the stored block is (lo, hi): transposed when the row's camera comes second; the diagonal block holds its upper triangle
+    const int e = br < bc ? a * 6 + b : br > bc ? b * 6 + a : (a <= b ? a * 6 + b : b * 6 + a);
+    off[k] = has[k] ? blk * 36 + e : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double v = P.Sblk[off[k]];
+    const int R = ti * kTile + r0 + k * rstep;
+    const bool real = ir[k] >= 0 && ic >= 0;
+    out[k] = has[k] ? v : (!real && R == C) ? 1.0 : 0.0;  // padding columns (tile alignment of the dissection's parts, tail of the last tile): identity
+    if (real && R == C) out[k] += fmin(fmax(P.diagU[ir[k]], P.min_diag), P.max_diag) / lm_radius;
+  }
+}
+// one workgroup (256 threads): tile (ti, tj) of the system and / or a zero for its inverse accumulator
+__device__ __forceinline__ void assemble_tile(const AssembleArgs& P, double lm_radius, int ti, int tj, bool write) {
+  const int64_t id = lt_tile(ti, tj);
+  if (P.Pinv && ti < P.nt && tj < ti)
+    for (int e = threadIdx.x; e < kTileElems; e += 256) P.Pinv[id * kTileElems + e] = 0.0;
+  if (!write) return;
+  double* T = P.A + id * kTileElems;
+  const int e = threadIdx.x;  // elements e + 256 k: rows (e >> 5) + 8 k, column e & 31
+  double v[4];
+  assemble_quad(P, lm_radius, ti, tj, e >> 5, 8, e & 31, v);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) T[e + 256 * k] = v[k];
+}
+
 // one workgroup per lower tile (including the rhs tile row)
 __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
   if (lm_over(P.ctl)) return;
@@ -26,38 +83,9 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs P) {
   while ((int64_t)ti * (ti + 1) / 2 > id) --ti;
   while ((int64_t)(ti + 1) * (ti + 2) / 2 <= id) ++ti;
   const int tj = (int)(id - (int64_t)ti * (ti + 1) / 2);
-  double* T = P.A + id * kTileElems;
-  const int n = P.n;
-  // the accumulators of the inverse propagation (see k_chol_step) start from zero
-  if (P.Pinv && ti < P.nt && tj < ti)
-    for (int e = threadIdx.x; e < kTileElems; e += 256) P.Pinv[id * kTileElems + e] = 0.0;
   if (P.y && blockIdx.x == 0)  // the solution vector is accumulated with atomics (k_inv_y): start from zero
     for (int e = threadIdx.x; e < P.n_vec; e += 256) P.y[e] = 0.0;
-  if (P.live && !P.live[id]) return;  // outside the symbolic factor: nobody reads this tile
-  for (int e = threadIdx.x; e < kTileElems; e += 256) {
-    const int r = e >> 5, c = e & 31;
-    const int C = tj * kTile + c;
-    double v = 0.0;
-    if (ti == P.nt) {
-      const int ic = vec_index(P.col_slot, C, n);
-      if (tj < P.nt && r == 0 && ic >= 0) v = P.wv[ic] - P.gc[ic];
-    } else {
-      const int R = ti * kTile + r;
-      const int ir = vec_index(P.col_slot, R, n), ic = vec_index(P.col_slot, C, n);
-      if (ir < 0 || ic < 0) {
-        v = (R == C) ? 1.0 : 0.0;  // padding columns (tile alignment of the dissection's parts, tail of the last tile): identity
-      } else {
-        const int br = ir / 6, a = ir - br * 6, bc = ic / 6, b = ic - bc * 6;
-        const int lo = br < bc ? br : bc, hi = br < bc ? bc : br;
-        if (!sky_has(P.sky, lo, hi)) v = 0.0;  // no landmark shared by the two cameras: structurally zero
-        else if (br < bc) v = P.Sblk[sky_block(P.sky, br, bc) * 36 + a * 6 + b];
-        else if (br > bc) v = P.Sblk[sky_block(P.sky, bc, br) * 36 + b * 6 + a];
-        else v = P.Sblk[sky_block(P.sky, br, br) * 36 + (a <= b ? a * 6 + b : b * 6 + a)];
-        if (R == C) v += fmin(fmax(P.diagU[ir], P.min_diag), P.max_diag) / lm_radius;
-      }
-    }
-    T[e] = v;
-  }
+  assemble_tile(P, lm_radius, ti, tj, !(P.live && !P.live[id]));
 }
 
 // C(32x32, C-layout accumulators) -= A(32x32) * B(32x32)^T, A/B row-major tiles in global memory.
