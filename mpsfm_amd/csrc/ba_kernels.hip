@@ -154,11 +154,15 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   __shared__ __attribute__((aligned(16))) double s_W[kObsMax * kWStride];
   __shared__ __attribute__((aligned(16))) double s_V[kPtsMax * 6];
   __shared__ double s_g[kPtsMax * 3];
-  __shared__ double s_U[kTileCams * 21];
-  __shared__ double s_gc[kTileCams * 6];
-  __shared__ double s_wv[kTileCams * 6];
+  // per-camera accumulators: neighbouring lanes are the records of ONE landmark, so a wave adds ~13 records to every camera of
+  // the chunk with one instruction — kCamCopies copies (chosen by the landmark) cut that same-address serialisation; P4 sums them
+  constexpr int kCamCopies = MPSFM_CAM_COPIES, kUCopy = kTileCams * 21 + 1, kGCopy = kTileCams * 6 + 1;
+  __shared__ double s_U[kCamCopies * kUCopy];
+  __shared__ double s_gc[kCamCopies * kGCopy];
+  __shared__ double s_wv[kCamCopies * kGCopy];
   __shared__ double s_du[kTileCams * 6];
   __shared__ int32_t s_slot[kLocalCamsMax];
+  __shared__ uint8_t s_const[kPtsMax];
   __shared__ double s_red[3 * (kThreads / 64)];
   __shared__ double s_stage[(kThreads / kPairGroup) * 36];
   __shared__ uint32_t s_ents[kEntStage];
@@ -170,9 +174,18 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   // ---- P0: clear accumulators, stage chunk tables -----------------------------------------
   for (int i = tid; i < kPtsMax * 6; i += kThreads) s_V[i] = 0.0;
   for (int i = tid; i < kPtsMax * 3; i += kThreads) s_g[i] = 0.0;
-  for (int i = tid; i < kTileCams * 21; i += kThreads) s_U[i] = 0.0;
-  if (tid < kTileCams * 6) { s_gc[tid] = 0.0; s_wv[tid] = 0.0; s_du[tid] = 0.0; }
+  for (int i = tid; i < kCamCopies * kUCopy; i += kThreads) s_U[i] = 0.0;
+  for (int i = tid; i < kCamCopies * kGCopy; i += kThreads) { s_gc[i] = 0.0; s_wv[i] = 0.0; }
+  if (tid < kTileCams * 6) s_du[tid] = 0.0;
   if (tid < ncam) s_slot[tid] = A.chunk_cams[H.cam0 + tid];
+  // what P2 needs of this thread's landmark is requested here, so that the loads are back when P1 is done
+  uint16_t my_kv = 0xffff;
+  double my_ps[3] = {1.0, 1.0, 1.0};
+  if (MODE == MODE_FULL && tid < npt) {
+    my_kv = A.pt_kv[H.pt0 + tid];
+    my_ps[0] = A.ps[3 * (H.pt0 + tid)]; my_ps[1] = A.ps[3 * (H.pt0 + tid) + 1]; my_ps[2] = A.ps[3 * (H.pt0 + tid) + 2];
+    s_const[tid] = my_kv == 0xffff;  // constant landmark: no Schur products (P3a)
+  }
   const bool dense = MODE == MODE_FULL && H.dense != 0 && !(A.dbg & 32);
   const bool ents_in_lds = (H.nent <= kEntStage);
   // dense chunks: record of every (landmark, local camera), 0xffff: none (256 records need 9 bits).  Lives in the entry
@@ -239,16 +252,17 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
         if (MODE == MODE_FULL) {
           // g_c and the upper triangle of U_c (21 values, packed row-major a <= b)
           double* gS = &A.Sblk[sky_block(A.sky, slot, slot) * 36];
+          const int copy = lpt % kCamCopies;
           int u = 0;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
             const double gci = L.Jc[i] * L.r[0] + L.Jc[6 + i] * L.r[1] + L.Jc[12 + i] * L.r[2];
-            if (lcam < kTileCams) atomicAdd(&s_gc[lcam * 6 + i], gci);
+            if (lcam < kTileCams) atomicAdd(&s_gc[copy * kGCopy + lcam * 6 + i], gci);
             else atomicAdd(&A.gc[(size_t)slot * 6 + i], gci);
 #pragma unroll
             for (int j = i; j < 6; ++j, ++u) {
               const double uij = L.Jc[i] * L.Jc[j] + L.Jc[6 + i] * L.Jc[6 + j] + L.Jc[12 + i] * L.Jc[12 + j];
-              if (lcam < kTileCams) atomicAdd(&s_U[lcam * 21 + u], uij);
+              if (lcam < kTileCams) atomicAdd(&s_U[copy * kUCopy + lcam * 21 + u], uij);
               else atomicAdd(&gS[i * 6 + j], uij);
             }
           }
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       A.diagV[3 * pix] = s_V[tid * 6];
       A.diagV[3 * pix + 1] = s_V[tid * 6 + 3];
       A.diagV[3 * pix + 2] = s_V[tid * 6 + 5];
-    } else if (A.pt_kv[pix] != 0xffff) {
+    } else if (my_kv != 0xffff) {
       // variable landmark (kv == 0xffff marks a constant one)
       double V[6], Vi[6];
 #pragma unroll
@@ -292,8 +306,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) s_V[tid * 6 + k] = Vi[k];
       s_g[tid * 3] = Vi[0] * g0; s_g[tid * 3 + 1] = Vi[1] * g0 + Vi[2] * g1; s_g[tid * 3 + 2] = Vi[3] * g0 + Vi[4] * g1 + Vi[5] * g2;  // F g
-      const double p0 = A.ps[3 * pix], p1 = A.ps[3 * pix + 1], p2 = A.ps[3 * pix + 2];
-      my_gmax = fmax(fabs(g0 / p0), fmax(fabs(g1 / p1), fabs(g2 / p2)));
+      my_gmax = fmax(fabs(g0 / my_ps[0]), fmax(fabs(g1 / my_ps[1]), fabs(g2 / my_ps[2])));
     }
   }
   if (MODE == MODE_FULL) {
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     if (tid < nrec) {
       const int lcam = my_meta & 0xff;
       const int lpt = (my_meta >> 8) & 0xff;
-      if (lcam != (int)kLcamConst && A.pt_kv[H.pt0 + lpt] != 0xffff) {
+      if (lcam != (int)kLcamConst && !s_const[lpt]) {
         double* w = &s_W[tid * kWStride];
         const double v0 = s_g[lpt * 3], v1 = s_g[lpt * 3 + 1], v2 = s_g[lpt * 3 + 2];
         const double f00 = s_V[lpt * 6], f10 = s_V[lpt * 6 + 1], f11 = s_V[lpt * 6 + 2], f20 = s_V[lpt * 6 + 3], f21 = s_V[lpt * 6 + 4],
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
           const double z0 = w0 * f00, z1 = w0 * f10 + w1 * f11, z2 = w0 * f20 + w1 * f21 + w2 * f22;
           w[i * 3] = z0; w[i * 3 + 1] = z1; w[i * 3 + 2] = z2;
           const double x = z0 * v0 + z1 * v1 + z2 * v2;
-          if (lcam < kTileCams) atomicAdd(&s_wv[lcam * 6 + i], x);
+          if (lcam < kTileCams) atomicAdd(&s_wv[(lpt % kCamCopies) * kGCopy + lcam * 6 + i], x);
           else atomicAdd(&A.wv[(size_t)slot * 6 + i], x);
         }
         if (dense && my_bad == 0) s_rec[lpt * kDenseCams + lcam] = (uint16_t)tid;  // this record's Z takes part in the products
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       typedef double v4d __attribute__((ext_vector_type(4)));
       const int lane = tid & 63, wave = tid >> 6;
       const int rc = lane & 15, kq = lane >> 4;
-      for (int i = tid; i < (kDenseCams * (kDenseCams + 1) / 2) * 36; i += kThreads) s_stage[i] = 0.0;
+      for (int i = tid; i < (ncam * (ncam + 1) / 2) * 36; i += kThreads) s_stage[i] = 0.0;
       int cam_of[3], a3_of[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) { const int r = 16 * t + rc; cam_of[t] = r / 6; a3_of[t] = (r - 6 * cam_of[t]) * 3; }
@@ -351,26 +364,41 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
           double x[3][3];
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
+            if (16 * t >= 6 * ncam) { x[t][0] = x[t][1] = x[t][2] = 0.0; continue; }
             const int rec = p < npt ? (int)s_rec[p * kDenseCams + cam_of[t]] : 0xffff;
             const double* z = &s_W[(rec == 0xffff ? 0 : rec) * kWStride + a3_of[t]];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { const double v = z[c]; x[t][c] = rec == 0xffff ? 0.0 : v; }
           }
+          // 6 ncam rows: up to two cameras fill one 16-row tile, up to five two (three of the six tile pairs)
+          if (ncam <= 2) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[0][c], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[1][c], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[2][c], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[1][c], acc[3], 0, 0, 0);
-            acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[2][c], acc[4], 0, 0, 0);
-            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2][c], x[2][c], acc[5], 0, 0, 0);
+            for (int c = 0; c < 3; ++c) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[0][c], acc[0], 0, 0, 0);
+          } else if (ncam <= 5) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[0][c], acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[1][c], acc[1], 0, 0, 0);
+              acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[1][c], acc[3], 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[0][c], acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[1][c], acc[1], 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[2][c], acc[2], 0, 0, 0);
+              acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[1][c], acc[3], 0, 0, 0);
+              acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[2][c], acc[4], 0, 0, 0);
+              acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2][c], x[2][c], acc[5], 0, 0, 0);
+            }
           }
         }
       // accumulator element r of lane l: row (l >> 4) + 4 r, column l & 15 of its tile pair
       {
         const int tis[6] = {0, 0, 0, 1, 1, 2}, tjs[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < 6; ++q) {
+          if (16 * tjs[q] >= 6 * ncam) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * tis[q] + kq + 4 * r, col = 16 * tjs[q] + rc;
@@ -380,6 +408,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
               if (v != 0.0) atomicAdd(&s_stage[(cj * (cj + 1) / 2 + ci) * 36 + (row - 6 * ci) * 6 + (col - 6 * cj)], v);
             }
           }
+        }
       }
       __syncthreads();
       if (!(A.dbg & 4)) {
@@ -461,7 +490,9 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   if (MODE == MODE_FULL) {
     for (int idx = tid; idx < kTileCams * 21; idx += kThreads) {
       const int lc = idx / 21;
-      const double v = s_U[idx];
+      double v = s_U[idx];
+#pragma unroll
+      for (int q = 1; q < kCamCopies; ++q) v += s_U[q * kUCopy + idx];
       if (lc < ncam && v != 0.0) {
         int u = idx - lc * 21, i = 0;
         while (u >= 6 - i) { u -= 6 - i; ++i; }  // packed (i, j >= i) -> i, j = i + u
@@ -476,8 +507,11 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
       const size_t o = (size_t)s_slot[lc] * 6 + (tid - lc * 6);
       if (MODE == MODE_DIAG && s_du[tid] != 0.0) atomicAdd(&A.diagU[o], s_du[tid]);
       if (MODE == MODE_FULL) {
-        if (s_gc[tid] != 0.0) atomicAdd(&A.gc[o], s_gc[tid]);
-        if (s_wv[tid] != 0.0) atomicAdd(&A.wv[o], s_wv[tid]);
+        double g = s_gc[tid], w = s_wv[tid];
+#pragma unroll
+        for (int q = 1; q < kCamCopies; ++q) { g += s_gc[q * kGCopy + tid]; w += s_wv[q * kGCopy + tid]; }
+        if (g != 0.0) atomicAdd(&A.gc[o], g);
+        if (w != 0.0) atomicAdd(&A.wv[o], w);
       }
     }
   }

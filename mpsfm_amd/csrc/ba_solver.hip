@@ -1130,6 +1130,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     const double n = (double)chunks.size();
     std::fprintf(stderr, "[mpsfm_ba] build: %zu chunks; per chunk: %.1f records, %.1f landmarks, %.1f cameras (max %d), %.1f work items (max %d), %.1f pairs; %.0f %% of the chunks take the dense product\n",
                  chunks.size(), sr / n, sp / n, sc / n, mc, sb / n, mb, se / n, 100.0 * sd / n);
+    int hist[kDenseCams + 2] = {0};
+    for (const ChunkHdr& H : chunks) ++hist[std::min<int>(H.ncam, kDenseCams + 1)];
+    std::fprintf(stderr, "[mpsfm_ba] build: chunks by number of variable cameras:");
+    for (int c = 0; c <= kDenseCams + 1; ++c) std::fprintf(stderr, " %s%d: %d", c > kDenseCams ? ">" : "", c > kDenseCams ? kDenseCams : c, hist[c]);
+    std::fprintf(stderr, "\n");
   }
   // -- which 6x6 blocks of S exist, and the tables of the dense factorisation
   if (use_graph) {

@@ -17,6 +17,9 @@ namespace mpsfm {
 #ifndef MPSFM_ITEM_PAIRS
 #define MPSFM_ITEM_PAIRS 64
 #endif
+#ifndef MPSFM_CAM_COPIES
+#define MPSFM_CAM_COPIES 3  // LDS copies of the per-camera accumulators of the track sweep
+#endif
 #ifndef MPSFM_ENT_STAGE
 #define MPSFM_ENT_STAGE 1024
 #endif
