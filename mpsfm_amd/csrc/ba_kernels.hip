@@ -538,8 +538,11 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
   if (lm_over(A.ctl)) return;
   const double lm_radius = A.ctl ? lm_radius_of(A.ctl) : A.radius;
-  __shared__ double s_V[kPtsMax * 6];
-  __shared__ double s_g[kPtsMax * 3];   // g_p + W^T y_c, then y_p
+  // kLmCopies copies of the landmark accumulators, chosen by the record's camera: the records of a landmark are neighbouring
+  // lanes, and same-address LDS atomics serialise
+  constexpr int kLmCopies = 3, kVCopy = kPtsMax * 6 + 2, kGCopy = kPtsMax * 3 + 2;
+  __shared__ double s_V[kLmCopies * kVCopy];
+  __shared__ double s_g[kLmCopies * kGCopy];   // g_p + W^T y_c, then y_p
   __shared__ double s_x2[kPtsMax * 3];  // candidate landmark
   __shared__ int32_t s_slot[kLocalCamsMax];
   __shared__ double s_red[5 * (kThreads / 64)];
@@ -547,8 +550,8 @@ __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
   const int tid = threadIdx.x;
   const ChunkHdr H = A.chunks[blockIdx.x];
   const int nrec = H.nrec, npt = H.npt, ncam = H.ncam;
-  for (int i = tid; i < kPtsMax * 6; i += kThreads) s_V[i] = 0.0;
-  for (int i = tid; i < kPtsMax * 3; i += kThreads) s_g[i] = 0.0;
+  for (int i = tid; i < kLmCopies * kVCopy; i += kThreads) s_V[i] = 0.0;
+  for (int i = tid; i < kLmCopies * kGCopy; i += kThreads) s_g[i] = 0.0;
   if (tid < ncam) s_slot[tid] = A.chunk_cams[H.cam0 + tid];
   __syncthreads();
 
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
     meta = A.rec_meta[rix];
     cam = A.rec_cam[rix];
     const int lcam = meta & 0xff;
+    const int copy = lcam % kLmCopies;
     lpt = (meta >> 8) & 0xff;
     xy = reinterpret_cast<const double2*>(A.rec_xy)[rix];
     if (meta & kRecHasDepth) { d = A.rec_d[rix]; m = A.rec_m[rix]; a = A.rec_a[rix]; }
@@ -591,9 +595,9 @@ __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
           g[0] += j0 * rr; g[1] += j1 * rr; g[2] += j2 * rr;
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&s_V[lpt * 6 + k], V[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&s_V[copy * kVCopy + lpt * 6 + k], V[k]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) atomicAdd(&s_g[lpt * 3 + k], g[k]);
+        for (int k = 0; k < 3; ++k) atomicAdd(&s_g[copy * kGCopy + lpt * 3 + k], g[k]);
       }
     }
   }
@@ -607,14 +611,25 @@ __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
     if (A.pt_kv[pix] != 0xffff) {
       double V[6], Vi[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) V[k] = s_V[tid * 6 + k];
+      for (int k = 0; k < 6; ++k) {
+        V[k] = s_V[tid * 6 + k];
+#pragma unroll
+        for (int q = 1; q < kLmCopies; ++q) V[k] += s_V[q * kVCopy + tid * 6 + k];
+      }
       V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / lm_radius;
       V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / lm_radius;
       V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / lm_radius;
       if (!spd3_inverse(V, Vi)) {
         ok = false;
       } else {
-        sym3_mul(Vi, -s_g[tid * 3], -s_g[tid * 3 + 1], -s_g[tid * 3 + 2], yp);
+        double gs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          gs[k] = s_g[tid * 3 + k];
+#pragma unroll
+          for (int q = 1; q < kLmCopies; ++q) gs[k] += s_g[q * kGCopy + tid * 3 + k];
+        }
+        sym3_mul(Vi, -gs[0], -gs[1], -gs[2], yp);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const double dl = A.ps[3 * pix + k] * yp[k];
