@@ -1231,16 +1231,52 @@ __device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* scal, c
 // single-workgroup launch instead of three.
 __global__ __launch_bounds__(kReduceThreads) void k_lm_reduce_decide(const double* part, const double* part2, int64_t rows, LmCtl* C, double* scal,
                                                                      LmOpts o, LmCtl* host_copy) {
-  __shared__ double s[8 * (kReduceThreads / 64)];
+  constexpr int kWaves = kReduceThreads / 64;
+  __shared__ double s[8 * kWaves];
+  __shared__ double s_out[8];
   const bool live = C->term == kLmRunning;
-  if (live && rows > 0) {
-    reduce_cols_block(part, rows, 4, 3, 1u << 2, scal + U_X_COST, nullptr, s);
-    reduce_cols_block(part2, rows, 8, 5, 0u, scal, nullptr, s);
+  // the scalars other kernels left (k_cam_update, the factorisation's failure flag): requested before the reductions
+  double sc[U_COUNT];
+  if (live && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < U_COUNT; ++i) sc[i] = __hip_atomic_load(scal + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past this CU's L1
   }
-  // One workgroup: barriers (workgroup-scope release / acquire) order the reductions' stores, the deciding thread's loads
-  // (write-through reads, below) and the copy; agent-scope fences here cost an L2 write-back each (2-6 us).
-  __syncthreads();
-  if (live && threadIdx.x == 0) lm_decide_thread(C, scal, o);
+  if (live && rows > 0) {
+    // both partial tables in one pass, eight columns: 0-2 track sweep (cost, bad count, gradient maximum), 3-7 update sweep.
+    // Fixed summation order (thread-strided rows, wave tree, then the wave results in order): deterministic run to run.
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t r = threadIdx.x; r < rows; r += kReduceThreads) {
+      const double a0 = part[r * 4], a1 = part[r * 4 + 1], a2 = part[r * 4 + 2];
+      const double b0 = part2[r * 8], b1 = part2[r * 8 + 1], b2 = part2[r * 8 + 2], b3 = part2[r * 8 + 3], b4 = part2[r * 8 + 4];
+      v[0] += a0; v[1] += a1; v[2] = fmax(v[2], a2);
+      v[3] += b0; v[4] += b1; v[5] += b2; v[6] += b3; v[7] += b4;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double w = c == 2 ? wave_max(v[c]) : wave_sum(v[c]);
+      if ((threadIdx.x & 63) == 0) s[c * kWaves + (threadIdx.x >> 6)] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      const double* p = &s[threadIdx.x * kWaves];
+      double r = p[0];
+      for (int w = 1; w < kWaves; ++w) r = threadIdx.x == 2 ? fmax(r, p[w]) : r + p[w];
+      s_out[threadIdx.x] = r;
+      scal[threadIdx.x < 3 ? U_X_COST + threadIdx.x : threadIdx.x - 3] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sc[c < 3 ? U_X_COST + c : c - 3] = s_out[c];
+    }
+  }
+  if (live && threadIdx.x == 0) {
+    LmHead L = *static_cast<const LmHead*>(C);
+    lm_decide_logic(L, C, sc, o);
+    *static_cast<LmHead*>(C) = L;
+  }
+  // one workgroup: the barrier (workgroup-scope release / acquire) orders the deciding thread's stores before the copy;
+  // agent-scope fences here cost an L2 write-back each (2-6 us)
   __syncthreads();
   if (host_copy) lm_copy_to_host(C, host_copy);
 }
