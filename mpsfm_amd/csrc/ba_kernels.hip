@@ -78,7 +78,7 @@ __device__ __forceinline__ void linearize_record(const double* __restrict__ cam,
     if (!(Zc > 0.0)) {
       o.ok = false;
     } else {
-      const double rd = log(Zc) - log(d);
+      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
       double rho0, rho1;
       loss_eval(L.depth_type, a, rd * rd, rho0, rho1);
       o.cost += 0.5 * m * rho0;
@@ -115,7 +115,7 @@ __device__ __forceinline__ double record_cost(const double* __restrict__ cam, co
     if (!(Zc > 0.0)) {
       ok = false;
     } else {
-      const double rd = log(Zc) - log(d);
+      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
       double rho0, rho1;
       loss_eval(L.depth_type, a, rd * rd, rho0, rho1);
       cost += 0.5 * m * rho0;

@@ -768,6 +768,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
             const int64_t s = (mid + k)->src;
             r.flags |= kRecHasDepth; r.d = deff(it->cam, s); r.m = P->dobs_magnitude[s]; r.a = P->dobs_param[s];
             if (!(r.d > 0.0)) { M.err = 2; return; }
+            r.d = std::log(r.d);  // the residual is log Z - log d: the records carry log d (one logarithm less per evaluation)
           }
           if (is_fixed) { M.fixed.push_back(r); M.fixed_pt.push_back(p); }
           else M.recs.push_back(r);

@@ -256,7 +256,7 @@ struct SweepArgs {
   const int32_t* rec_cam;        // camera index (camera table row)
   const uint32_t* rec_meta;      // lcam | lpt<<8 | flags<<16
   const double* rec_xy;          // [nrec][2]
-  const double* rec_d;           // effective prior depth d*exp(s)+b
+  const double* rec_d;           // log of the effective prior depth d*exp(s)+b
   const double* rec_m;           // depth loss magnitude
   const double* rec_a;           // depth loss scale
   const int32_t* pt_rec_start;   // [np+1]
