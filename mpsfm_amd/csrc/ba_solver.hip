@@ -5,7 +5,9 @@
 // ba_kernels.hip / dense_chol.hip; this file only orders launches and takes the accept/reject
 // decisions from a handful of scalars.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -15,10 +17,12 @@
 #include <string>
 #include <thread>
 #include <tuple>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
 #include <dlfcn.h>
+#include <pthread.h>
 #include <sched.h>
 
 #include "common.h"
@@ -326,14 +330,59 @@ static int dev_upload(T** p, const std::vector<T>& v) {
   if ((rc = G.init())) return rc;
   return G.push(*p, v.data(), v.size() * sizeof(T));  // build() drains once after the last table
 }
-// uninitialised host array (std::vector would zero-fill tens of MB on one thread)
+// Large host blocks of the table build come from a process-wide cache: a fresh 40 MB block costs its page faults on first
+// touch and an munmap on release (several ms per create at C3); a recycled one costs neither.  Power-of-two buckets from
+// 1 MB, at most kHostCacheBytes kept.
+struct HostBlockCache {
+  static constexpr size_t kMinBytes = size_t(1) << 20, kHostCacheBytes = size_t(512) << 20;
+  std::mutex mu;
+  std::vector<std::pair<size_t, void*>> free_blocks;
+  size_t cached = 0;
+  static size_t bucket(size_t bytes) { size_t b = kMinBytes; while (b < bytes) b <<= 1; return b; }
+  void* take(size_t bytes, size_t& got) {
+    if (bytes < kMinBytes) { got = 0; return ::operator new(std::max<size_t>(bytes, 1)); }
+    got = bucket(bytes);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < free_blocks.size(); ++i)
+        if (free_blocks[i].first == got) {
+          void* p = free_blocks[i].second;
+          free_blocks[i] = free_blocks.back(); free_blocks.pop_back();
+          cached -= got;
+          return p;
+        }
+    }
+    return ::operator new(got);
+  }
+  void give(void* p, size_t got) {
+    if (!p) return;
+    if (got) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (cached + got <= kHostCacheBytes) { free_blocks.emplace_back(got, p); cached += got; return; }
+    }
+    ::operator delete(p);
+  }
+  ~HostBlockCache() { for (auto& b : free_blocks) ::operator delete(b.second); }
+};
+static HostBlockCache& host_cache() { static HostBlockCache c; return c; }
+
+// uninitialised host array of trivially copyable elements (std::vector would zero-fill tens of MB on one thread)
 template <typename T>
 struct HostBuf {
-  std::unique_ptr<T[]> p;
-  size_t n = 0;
-  void alloc(size_t k) { p.reset(new T[std::max<size_t>(k, 1)]); n = k; }
+  static_assert(std::is_trivially_copyable<T>::value && std::is_trivially_destructible<T>::value, "HostBuf holds raw storage");
+  T* p = nullptr;
+  size_t n = 0, got = 0;
+  HostBuf() = default;
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+  ~HostBuf() { host_cache().give(p, got); }
+  void alloc(size_t k) {
+    host_cache().give(p, got);
+    p = static_cast<T*>(host_cache().take(std::max<size_t>(k, 1) * sizeof(T), got));
+    n = k;
+  }
   size_t size() const { return n; }
-  T* data() { return p.get(); }
+  T* data() { return p; }
   T& operator[](size_t i) { return p[i]; }
 };
 template <typename T>
@@ -526,9 +575,99 @@ static int host_threads() {
   }();
   return n;
 }
+// Persistent workers for the phases of the table build: creating and joining 15 threads costs ~0.4 ms, and one create runs
+// a dozen phases.  One job at a time; a caller that finds the pool busy (another handle being created) starts plain threads
+// as before.  Parts are claimed with the job's generation, so a worker that wakes late never touches a newer job; a forked
+// child starts over with a pool of its own (the parent's workers do not exist there).
+class HostPool {
+ public:
+  typedef void (*Call)(void* ctx, int part, int nparts);
+  // false: the pool is busy, nothing ran
+  bool try_run(int nparts, Call call, void* ctx) {
+    std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+    if (!job.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (workers_.empty()) {
+        const int nw = std::max(host_threads() - 1, 1);
+        for (int i = 0; i < nw; ++i) workers_.emplace_back([this] { work(); });
+      }
+      call_ = call; ctx_ = ctx; nparts_ = nparts;
+      done_.store(0, std::memory_order_relaxed);
+      ++gen_;
+      state_.store((gen_ << 32) | 1u, std::memory_order_release);  // part 0 is the caller's
+    }
+    cv_work_.notify_all();
+    call(ctx, 0, nparts);
+    finish_part();
+    claim_loop(gen_, call, ctx, nparts);
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return done_.load(std::memory_order_acquire) == nparts; });
+    return true;
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_work_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+
+ private:
+  void finish_part() {
+    if (done_.fetch_add(1, std::memory_order_acq_rel) + 1 == nparts_) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
+  }
+  void claim_loop(uint64_t gen, Call call, void* ctx, int nparts) {
+    uint64_t s = state_.load(std::memory_order_acquire);
+    while ((s >> 32) == gen && (int)(s & 0xffffffffu) < nparts) {
+      if (state_.compare_exchange_weak(s, s + 1, std::memory_order_acq_rel)) {
+        call(ctx, (int)(s & 0xffffffffu), nparts);
+        finish_part();
+        s = state_.load(std::memory_order_acquire);
+      }
+    }
+  }
+  void work() {
+    uint64_t seen = 0;
+    for (;;) {
+      Call call; void* ctx; int nparts; uint64_t gen;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_work_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen = gen_; call = call_; ctx = ctx_; nparts = nparts_;
+      }
+      claim_loop(gen, call, ctx, nparts);
+    }
+  }
+  std::mutex job_mu_, mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::vector<std::thread> workers_;
+  std::atomic<uint64_t> state_{0};
+  std::atomic<int> done_{0};
+  uint64_t gen_ = 0;
+  Call call_ = nullptr; void* ctx_ = nullptr; int nparts_ = 0;
+  bool stop_ = false;
+};
+static std::atomic<HostPool*> g_host_pool{nullptr};
+static HostPool* host_pool() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    pthread_atfork(nullptr, nullptr, [] { g_host_pool.store(nullptr); });  // child: the old pool is abandoned, never destroyed
+    std::atexit([] { delete g_host_pool.exchange(nullptr); });
+  });
+  HostPool* p = g_host_pool.load(std::memory_order_acquire);
+  if (!p) {
+    HostPool* fresh = new HostPool();
+    if (g_host_pool.compare_exchange_strong(p, fresh)) p = fresh; else delete fresh;
+  }
+  return p;
+}
 // f(part, nparts) on nparts threads (the calling thread takes part 0)
 template <class F>
 static void run_parts(int nparts, F&& f) {
+  if (nparts <= 1) { f(0, std::max(nparts, 1)); return; }
+  static const bool use_pool = !(std::getenv("MPSFM_HOST_POOL") && std::atoi(std::getenv("MPSFM_HOST_POOL")) == 0);
+  typedef typename std::remove_reference<F>::type Fn;
+  if (use_pool && host_pool()->try_run(nparts, [](void* c, int t, int n) { (*static_cast<Fn*>(c))(t, n); }, const_cast<void*>(static_cast<const void*>(&f)))) return;
   std::vector<std::thread> th;
   th.reserve((size_t)std::max(nparts - 1, 0));
   for (int t = 1; t < nparts; ++t) th.emplace_back([&f, t, nparts] { f(t, nparts); });
