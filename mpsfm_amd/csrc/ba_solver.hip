@@ -1788,6 +1788,24 @@ static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, cons
 }  // namespace mpsfm
 
 // ---- C ABI ---------------------------------------------------------------------------------------
+// Test hook (tests/test_host_cpu.py; no device involved): `reps` rounds of an `nparts`-part job through the table build's
+// worker pool; returns the number of parts that did not run exactly once.
+extern "C" int64_t mpsfm_debug_run_parts(int32_t nparts, int32_t reps) {
+  int64_t bad = 0;
+  for (int r = 0; r < reps; ++r) {
+    std::vector<std::atomic<int>> hits((size_t)std::max(nparts, 1));
+    for (auto& x : hits) x.store(0);
+    mpsfm::run_parts(nparts, [&](int t, int np) {
+      if (np != std::max(nparts, 1) || t < 0 || t >= np) return;
+      volatile double acc = 0.0;
+      for (int k = 0; k < 2000; ++k) acc = acc + (double)k * 1e-9;  // a little work, so that parts overlap
+      hits[(size_t)t].fetch_add(1);
+    });
+    for (auto& x : hits) bad += x.load() == 1 ? 0 : 1;
+  }
+  return bad;
+}
+
 extern "C" {
 
 int mpsfm_abi_version(void) { return MPSFM_ABI_VERSION; }

@@ -194,3 +194,42 @@ def test_local_window_helper_equals_the_shims_local_assembly():
     shim_blocks = blocks(p, [i - ids[0] for i in flat.image_ids], flat.point_ids)
     loc_blocks = blocks(loc, cams, [pid_of[int(g)] for g in pts])
     assert shim_blocks == loc_blocks
+
+
+def _run_parts(nparts, reps):
+    import ctypes as C
+
+    from mpsfm_amd import capi
+
+    L = capi.lib()
+    L.mpsfm_debug_run_parts.restype = C.c_int64
+    L.mpsfm_debug_run_parts.argtypes = [C.c_int32, C.c_int32]
+    return int(L.mpsfm_debug_run_parts(nparts, reps))
+
+
+def test_table_build_worker_pool_runs_every_part_once():
+    """The persistent workers of the table build (csrc/ba_solver.hip: HostPool): every part of every job exactly once, for
+    more parts than workers, for concurrent callers (the second finds the pool busy and starts plain threads) and in a forked
+    child (which must not wait for the parent's workers)."""
+    import os
+    import threading
+
+    for nparts in (1, 2, 7, 16, 61):
+        assert _run_parts(nparts, 50) == 0
+    out = []
+    ths = [threading.Thread(target=lambda: out.append(_run_parts(9, 300))) for _ in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert out == [0, 0, 0, 0]
+    pid = os.fork()
+    if pid == 0:
+        rc = 1
+        try:
+            rc = 0 if _run_parts(8, 20) == 0 else 2
+        finally:
+            os._exit(rc)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    assert _run_parts(8, 20) == 0
