@@ -420,9 +420,19 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
           while ((cj + 1) * (cj + 2) / 2 <= b) ++cj;
           const int ci = b - cj * (cj + 1) / 2;
           const int ra = el / 6, cb = el - ra * 6;
-          const double v = s_stage[idx];
-          if (v != 0.0 && (ci != cj || cb >= ra))  // diagonal blocks keep their upper triangle only
-            atomicAdd(&A.Sblk[sky_block(A.sky, s_slot[ci], s_slot[cj]) * 36 + el], -v);
+          double v = -s_stage[idx];
+          if (ci == cj) {
+            // diagonal blocks keep their upper triangle only; the camera's own U block goes out with the same atomic (its
+            // diagonal also into diag U) instead of a second pass over the same addresses in P4
+            if (cb < ra) continue;
+            const int u = ra * 6 - (ra * (ra - 1)) / 2 + (cb - ra);
+            double uu = 0.0;
+#pragma unroll
+            for (int q = 0; q < kCamCopies; ++q) uu += s_U[q * kUCopy + ci * 21 + u];
+            v += uu;
+            if (ra == cb && uu != 0.0) atomicAdd(&A.diagU[(size_t)s_slot[ci] * 6 + ra], uu);
+          }
+          if (v != 0.0) atomicAdd(&A.Sblk[sky_block(A.sky, s_slot[ci], s_slot[cj]) * 36 + el], v);
         }
       }
     } else
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   __syncthreads();
 
   // ---- P4: flush the per-camera LDS accumulators, chunk partials ------------------------------
-  if (MODE == MODE_FULL) {
+  if (MODE == MODE_FULL && !dense) {  // dense chunks have sent U with their diagonal Schur blocks
     for (int idx = tid; idx < kTileCams * 21; idx += kThreads) {
       const int lc = idx / 21;
       double v = s_U[idx];
