@@ -204,6 +204,11 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   double my_cost = 0.0;
   int my_bad = 0;
   uint32_t my_meta = 0;
+  // W = Jc^T Jp (6x3) of this thread's record stays in registers until P3a turns it into Z (two workgroups per CU by LDS:
+  // registers are not what limits occupancy)
+  double my_w[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) my_w[i] = 0.0;
   if (tid < nrec) {
     const int rix = H.rec0 + tid;
     const uint32_t meta = A.rec_meta[rix];
@@ -266,13 +271,11 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
               else atomicAdd(&gS[i * 6 + j], uij);
             }
           }
-          // W = Jc^T Jp (6x3) stays in LDS
-          double* w = &s_W[tid * kWStride];
 #pragma unroll
           for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-              w[i * 3 + j] = L.Jc[i] * L.Jp[j] + L.Jc[6 + i] * L.Jp[3 + j] + L.Jc[12 + i] * L.Jp[6 + j];
+              my_w[i * 3 + j] = L.Jc[i] * L.Jp[j] + L.Jc[6 + i] * L.Jp[3 + j] + L.Jc[12 + i] * L.Jp[6 + j];
         }
       }
     }
@@ -324,8 +327,8 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
         const int slot = s_slot[lcam];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          // W -> Z = W F^T in place (this thread owns the row block of its record)
-          const double w0 = w[i * 3], w1 = w[i * 3 + 1], w2 = w[i * 3 + 2];
+          // W -> Z = W F^T, into the record's row block in LDS
+          const double w0 = my_w[i * 3], w1 = my_w[i * 3 + 1], w2 = my_w[i * 3 + 2];
           const double z0 = w0 * f00, z1 = w0 * f10 + w1 * f11, z2 = w0 * f20 + w1 * f21 + w2 * f22;
           w[i * 3] = z0; w[i * 3 + 1] = z1; w[i * 3 + 2] = z2;
           const double x = z0 * v0 + z1 * v1 + z2 * v2;
