@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     my_ps[0] = A.ps[3 * (H.pt0 + tid)]; my_ps[1] = A.ps[3 * (H.pt0 + tid) + 1]; my_ps[2] = A.ps[3 * (H.pt0 + tid) + 2];
     s_const[tid] = my_kv == 0xffff;  // constant landmark: no Schur products (P3a)
   }
-  const bool dense = MODE == MODE_FULL && H.dense != 0 && !(A.dbg & 32);
+  const bool dense = MODE == MODE_FULL && H.dense != 0 && !(A.dbg & 32);  // ablation flag 32: the products of dense chunks are dropped (they have no pair tables to fall back on)
   const bool ents_in_lds = (H.nent <= kEntStage);
   // dense chunks: record of every (landmark, local camera), 0xffff: none (256 records need 9 bits).  Lives in the entry
   // stage, which they do not use.
