@@ -332,9 +332,13 @@ static int dev_upload(T** p, const std::vector<T>& v) {
 }
 // Large host blocks of the table build come from a process-wide cache: a fresh 40 MB block costs its page faults on first
 // touch and an munmap on release (several ms per create at C3); a recycled one costs neither.  Power-of-two buckets from
-// 1 MB, at most kHostCacheBytes kept.
+// 1 MB, at most 512 MB kept (MPSFM_HOST_CACHE_MB).
 struct HostBlockCache {
-  static constexpr size_t kMinBytes = size_t(1) << 20, kHostCacheBytes = size_t(512) << 20;
+  static constexpr size_t kMinBytes = size_t(1) << 20;
+  const size_t kHostCacheBytes = [] {  // MPSFM_HOST_CACHE_MB: how much released host memory is kept for the next build (0: none)
+    const char* e = std::getenv("MPSFM_HOST_CACHE_MB");
+    return (size_t)((e && std::atoi(e) >= 0) ? std::atoi(e) : 512) << 20;
+  }();
   std::mutex mu;
   std::vector<std::pair<size_t, void*>> free_blocks;
   size_t cached = 0;
