@@ -1792,6 +1792,22 @@ static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, cons
 }  // namespace mpsfm
 
 // ---- C ABI ---------------------------------------------------------------------------------------
+// Test hook (tests/test_host_cpu.py; no device involved): takes and gives back `count` host blocks of `bytes` each through
+// the block cache twice; returns how many blocks of the second round were recycled ones of the first (by address).
+extern "C" int64_t mpsfm_debug_host_cache(int64_t bytes, int32_t count) {
+  std::vector<mpsfm::HostBuf<uint8_t>> first((size_t)count), second((size_t)count);
+  std::vector<const void*> seen;
+  for (auto& b : first) { b.alloc((size_t)bytes); b[0] = 1; b[(size_t)bytes - 1] = 2; seen.push_back(b.data()); }
+  first.clear();
+  int64_t reused = 0;
+  for (auto& b : second) {
+    b.alloc((size_t)bytes);
+    b[0] = 3;
+    reused += std::find(seen.begin(), seen.end(), (const void*)b.data()) != seen.end() ? 1 : 0;
+  }
+  return reused;
+}
+
 // Test hook (tests/test_host_cpu.py; no device involved): `reps` rounds of an `nparts`-part job through the table build's
 // worker pool; returns the number of parts that did not run exactly once.
 extern "C" int64_t mpsfm_debug_run_parts(int32_t nparts, int32_t reps) {

@@ -233,3 +233,19 @@ def test_table_build_worker_pool_runs_every_part_once():
     _, status = os.waitpid(pid, 0)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     assert _run_parts(8, 20) == 0
+
+
+def test_table_build_host_blocks_are_recycled():
+    """Large host blocks of the table build come back from the process-wide cache (csrc/ba_solver.hip: HostBlockCache);
+    small ones bypass it."""
+    import ctypes as C
+
+    from mpsfm_amd import capi
+
+    L = capi.lib()
+    L.mpsfm_debug_host_cache.restype = C.c_int64
+    L.mpsfm_debug_host_cache.argtypes = [C.c_int64, C.c_int32]
+    assert L.mpsfm_debug_host_cache(3 << 20, 4) == 4      # 3 MB blocks (4 MB buckets): all four recycled
+    assert L.mpsfm_debug_host_cache(3 << 20, 4) == 4      # and again from the same cache
+    assert L.mpsfm_debug_host_cache(5 << 20, 2) == 2      # another bucket
+    L.mpsfm_debug_host_cache(1000, 8)                      # below the cache's minimum: plain new / delete, any answer is fine
