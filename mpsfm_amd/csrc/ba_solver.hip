@@ -385,9 +385,12 @@ struct HostBuf {
     p = static_cast<T*>(host_cache().take(std::max<size_t>(k, 1) * sizeof(T), got));
     n = k;
   }
+  void release() { host_cache().give(p, got); p = nullptr; n = got = 0; }
   size_t size() const { return n; }
   T* data() { return p; }
+  const T* data() const { return p; }
   T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
 };
 template <typename T>
 static int dev_upload(T** p, HostBuf<T>& v) {
@@ -762,8 +765,10 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   struct MergePart {
     int p0 = 0, p1 = 0, err = 0;
     std::vector<int64_t> pstart;  // block range of every landmark of the part
-    std::vector<Blk> blks;
-    std::vector<Rec> recs, fixed;
+    HostBuf<Blk> blks;   // recycled, uninitialised blocks (HostBlockCache): a few MB per part
+    HostBuf<Rec> recs;   // capacity = the part's blocks (merging only removes); nrecs filled
+    size_t nrecs = 0;
+    std::vector<Rec> fixed;
     std::vector<int32_t> fixed_pt;
     std::vector<int64_t> nrec_of;  // records per landmark of the range
   };
@@ -779,7 +784,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     for (int64_t i = 0; i < P->n_obs; ++i) { const unsigned q = (unsigned)(P->obs_pt[i] - p0); if (q < (unsigned)np_loc) pstart[q + 1]++; }
     for (int64_t i = 0; i < P->n_dobs; ++i) { const unsigned q = (unsigned)(P->dobs_pt[i] - p0); if (q < (unsigned)np_loc) pstart[q + 1]++; }
     for (int q = 0; q < np_loc; ++q) pstart[q + 1] += pstart[q];
-    M.blks.resize((size_t)pstart[np_loc]);
+    M.blks.alloc((size_t)pstart[np_loc]);
     std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
     for (int64_t i = 0; i < P->n_obs; ++i) {
       const unsigned q = (unsigned)(P->obs_pt[i] - p0);
@@ -883,20 +888,21 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   run_parts(mparts, [&](int t, int) {
     MergePart& M = mp[(size_t)t];
     const int p0 = M.p0, np_loc = M.p1 - M.p0;
-    std::vector<Blk>& blks = M.blks;
-    for (Blk& bk : blks) bk.key = slot[(size_t)bk.cam] < 0 ? INT32_MAX : slot[(size_t)bk.cam];
-    M.recs.reserve(blks.size());
+    Blk* const blks = M.blks.data();
+    for (size_t q = 0; q < M.blks.size(); ++q) blks[q].key = slot[(size_t)blks[q].cam] < 0 ? INT32_MAX : slot[(size_t)blks[q].cam];
+    M.recs.alloc(M.blks.size());
+    M.nrecs = 0;
     M.nrec_of.assign((size_t)np_loc, 0);
     for (int q = 0; q < np_loc; ++q) {
       const int p = p0 + q;
-      auto b0 = blks.begin() + M.pstart[(size_t)q], b1 = blks.begin() + M.pstart[(size_t)q + 1];
+      Blk* const b0 = blks + M.pstart[(size_t)q]; Blk* const b1 = blks + M.pstart[(size_t)q + 1];
       std::sort(b0, b1, [](const Blk& x, const Blk& y) {
         if (x.key != y.key) return x.key < y.key;
         if (x.cam != y.cam) return x.cam < y.cam;
         if (x.kind != y.kind) return x.kind < y.kind;
         return x.src < y.src;
       });
-      const size_t before = M.recs.size();
+      const size_t before = M.nrecs;
       for (auto it = b0; it != b1;) {
         auto je = it;
         while (je != b1 && je->cam == it->cam) ++je;
@@ -914,13 +920,13 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
             r.d = std::log(r.d);  // the residual is log Z - log d: the records carry log d (one logarithm less per evaluation)
           }
           if (is_fixed) { M.fixed.push_back(r); M.fixed_pt.push_back(p); }
-          else M.recs.push_back(r);
+          else M.recs[M.nrecs++] = r;
         }
         it = je;
       }
-      M.nrec_of[(size_t)q] = (int64_t)(M.recs.size() - before);
+      M.nrec_of[(size_t)q] = (int64_t)(M.nrecs - before);
     }
-    std::vector<Blk>().swap(M.blks);
+    M.blks.release();
   });
   for (const MergePart& M : mp)
     if (M.err == 2) return fail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive");
@@ -931,14 +937,14 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   std::vector<int32_t> fixed_pt;
   {
     std::vector<int64_t> base((size_t)mparts + 1, 0);
-    for (int t = 0; t < mparts; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)mp[(size_t)t].recs.size();
+    for (int t = 0; t < mparts; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)mp[(size_t)t].nrecs;
     recs.alloc((size_t)base[(size_t)mparts]);
     run_parts(mparts, [&](int t, int) {
       MergePart& M = mp[(size_t)t];
-      std::copy(M.recs.begin(), M.recs.end(), recs.data() + base[(size_t)t]);
+      std::copy(M.recs.data(), M.recs.data() + M.nrecs, recs.data() + base[(size_t)t]);
       int64_t o = base[(size_t)t];
       for (int q = 0; q < M.p1 - M.p0; ++q) { prec[(size_t)(M.p0 + q)] = o; o += M.nrec_of[(size_t)q]; }
-      std::vector<Rec>().swap(M.recs);
+      M.recs.release();
     });
     prec[(size_t)npu] = base[(size_t)mparts];
     for (MergePart& M : mp) {
