@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 import numpy as np
 from mpsfm_amd import capi
 from mpsfm_amd.synthetic import make_scene
-for ncam, npts in ((6, 1500), (12, 4000), (24, 10000)):
+for ncam, npts in ((6, 1500), (7, 1800), (10, 3000), (12, 4000), (24, 10000)):
     prob, _ = make_scene(ncam, npts, True, seed=3)
     h = capi.BAHandle(prob)
     for _ in range(3):
