@@ -94,6 +94,75 @@ __device__ __forceinline__ void linearize_record(const double* __restrict__ cam,
   }
 }
 
+// The update sweep's view of a record: rows of Jp, the robustified residuals and mrow = Jc yc, with the camera Jacobian
+// folded into the products (ys = cs .* yc) instead of materialised — 36 registers less at the kernel's pressure peak, which
+// is what held it at four waves per SIMD — and without the loss value (one logarithm less per Cauchy block).
+struct RecUpd {
+  double Jp[9], r[3], mrow[3];
+  bool ok;
+};
+__device__ __forceinline__ void linearize_update(const double* __restrict__ cam, const double* X, const double* psc, uint32_t meta, double u, double v,
+                                                 double d, double m, double a, const LossParams& L, const double* yc, RecUpd& o) {
+  double c[24];
+  const double2* c2 = reinterpret_cast<const double2*>(cam);
+#pragma unroll
+  for (int i = 0; i < 11; ++i) { const double2 t = c2[i]; c[2 * i] = t.x; c[2 * i + 1] = t.y; }
+  const double* R = c; const double* t = c + 9; const double* K = c + 12; const double* cs = c + 16;
+  const double Y0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+  const double Y1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+  const double Y2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+  const double Xc = Y0 + t[0], Yc = Y1 + t[1], Zc = Y2 + t[2];
+  const double iz = 1.0 / Zc;
+  double ys[6] = {0, 0, 0, 0, 0, 0};
+  if (yc) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ys[k] = cs[k] * yc[k];
+  }
+  o.ok = true;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.Jp[i] = 0.0;
+  o.r[0] = o.r[1] = o.r[2] = 0.0;
+  o.mrow[0] = o.mrow[1] = o.mrow[2] = 0.0;
+  if (meta & kRecHasReproj) {
+    const double r0 = K[0] * Xc * iz + K[2] - u;
+    const double r1 = K[1] * Yc * iz + K[3] - v;
+    double rho0, rho1;
+    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
+    o.ok = o.ok && isfinite(r0) && isfinite(r1);
+    const double w = sqrt(L.reproj_mag * rho1);
+    const double a00 = w * K[0] * iz, a02 = -w * K[0] * Xc * iz * iz;
+    const double a11 = w * K[1] * iz, a12 = -w * K[1] * Yc * iz * iz;
+    o.r[0] = w * r0; o.r[1] = w * r1;
+    // the rows of Jc as in linearize_record, times ys
+    o.mrow[0] = a02 * (2 * Y1) * ys[0] + (a00 * (2 * Y2) - a02 * (2 * Y0)) * ys[1] + (-a00 * (2 * Y1)) * ys[2] + a00 * ys[3] + a02 * ys[5];
+    o.mrow[1] = (a12 * (2 * Y1) - a11 * (2 * Y2)) * ys[0] + (-a12 * (2 * Y0)) * ys[1] + a11 * (2 * Y0) * ys[2] + a11 * ys[4] + a12 * ys[5];
+    o.Jp[0] = (a00 * R[0] + a02 * R[6]) * psc[0];
+    o.Jp[1] = (a00 * R[1] + a02 * R[7]) * psc[1];
+    o.Jp[2] = (a00 * R[2] + a02 * R[8]) * psc[2];
+    o.Jp[3] = (a11 * R[3] + a12 * R[6]) * psc[0];
+    o.Jp[4] = (a11 * R[4] + a12 * R[7]) * psc[1];
+    o.Jp[5] = (a11 * R[5] + a12 * R[8]) * psc[2];
+  }
+  if (meta & kRecHasDepth) {
+    if (!(Zc > 0.0)) {
+      o.ok = false;
+    } else {
+      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
+      // the robust weight alone (loss_eval's rho1): the loss value is not needed here
+      double rho1 = 1.0;
+      if (L.depth_type == MPSFM_LOSS_SOFT_L1) rho1 = fmax(DBL_MIN, 1.0 / sqrt(1.0 + rd * rd * (1.0 / (a * a))));
+      else if (L.depth_type == MPSFM_LOSS_CAUCHY) rho1 = fmax(DBL_MIN, 1.0 / (1.0 + rd * rd * (1.0 / (a * a))));
+      const double sw = sqrt(m * rho1);
+      const double w = sw * iz;
+      o.r[2] = sw * rd;
+      o.mrow[2] = w * (2 * Y1) * ys[0] + (-w * (2 * Y0)) * ys[1] + w * ys[5];
+      o.Jp[6] = w * R[6] * psc[0];
+      o.Jp[7] = w * R[7] * psc[1];
+      o.Jp[8] = w * R[8] * psc[2];
+    }
+  }
+}
+
 // cost only (candidate point)
 __device__ __forceinline__ double record_cost(const double* __restrict__ cam, const double* X, uint32_t meta,
                                               double u, double v, double d, double m, double a,
@@ -548,7 +617,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 // -----------------------------------------------------------------------------------------------
 // Update sweep: y_p = -(V+D)^-1 (g_p + W^T y_c), model cost change, candidate landmarks, candidate
 // cost.  Recomputes the linearisation (cheaper than storing 240 B per record in HBM).
-__global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
+__global__ __launch_bounds__(kThreads, 5) void k_update_sweep(SweepArgs A) {
   if (lm_over(A.ctl)) return;
   const double lm_radius = A.ctl ? lm_radius_of(A.ctl) : A.radius;
   // kLmCopies copies of the landmark accumulators, chosen by the record's camera: the records of a landmark are neighbouring
@@ -568,7 +637,7 @@ __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
   if (tid < ncam) s_slot[tid] = A.chunk_cams[H.cam0 + tid];
   __syncthreads();
 
-  RecLin L;
+  RecUpd L;
   double mrow[3] = {0, 0, 0};
   uint32_t meta = 0;
   int cam = 0, lpt = 0;
@@ -587,17 +656,11 @@ __global__ __launch_bounds__(kThreads) void k_update_sweep(SweepArgs A) {
     const int pix = H.pt0 + lpt;
     const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
     const double psc[3] = {A.ps[3 * pix], A.ps[3 * pix + 1], A.ps[3 * pix + 2]};
-    linearize_record(A.camtab + (size_t)cam * kCamRec, X, psc, meta, xy.x, xy.y, d, m, a, A.loss, L);
+    linearize_update(A.camtab + (size_t)cam * kCamRec, X, psc, meta, xy.x, xy.y, d, m, a, A.loss,
+                     lcam != (int)kLcamConst ? A.yc + (size_t)s_slot[lcam] * 6 : nullptr, L);
     ok = L.ok;
     if (L.ok) {
-      if (lcam != (int)kLcamConst) {
-        const double* y = A.yc + (size_t)s_slot[lcam] * 6;
-        const double y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3], y4 = y[4], y5 = y[5];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-          mrow[r] = L.Jc[6 * r] * y0 + L.Jc[6 * r + 1] * y1 + L.Jc[6 * r + 2] * y2 + L.Jc[6 * r + 3] * y3 +
-                    L.Jc[6 * r + 4] * y4 + L.Jc[6 * r + 5] * y5;
-      }
+      mrow[0] = L.mrow[0]; mrow[1] = L.mrow[1]; mrow[2] = L.mrow[2];
       if (psc[0] != 0.0) {
         double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
 #pragma unroll
