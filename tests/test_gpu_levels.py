@@ -20,6 +20,9 @@ VARIANTS = {
     "depth3": {"MPSFM_CHOL_ND": "3"},
     "no_graph_skyline": {"MPSFM_CHOL_GRAPH": "0"},
     "depth2_backward_by_levels": {"MPSFM_CHOL_ND": "2", "MPSFM_CHOL_INVERSE": "0"},
+    # not a slot order: every chunk forms its Schur blocks from the pair lists (the default does so only for chunks of more
+    # than eight cameras, the others take the dense product on the matrix pipe) — the same S and rhs either way
+    "sweep_pair_lists": {"MPSFM_SWEEP_DENSE": "0"},
 }
 
 
