@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')
 from mpsfm_amd.synthetic import make_scene
 from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
-from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+from numpy_scene import scene_from_problem
 prob, truth = make_scene(40, 30000, True, seed=5)
 sc = scene_from_problem(prob, truth, seed=1)
 og = Optimizer({}, sc, None)

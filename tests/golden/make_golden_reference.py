@@ -17,7 +17,7 @@ reference travels — the fixtures hold inputs and outputs, no source text):
     fit_robust_gaussian_mad                                                                       (a-7)
     Optimizer.update_truncation_multiplier                                                        (a-7)
     Optimizer.__yield_problem_parameters, __build_shiftscale_problem, optimize_prior_shiftscale   (a-8)
-  These run on the repo's NumPy scene (mpsfm_amd/sfm/scene/numpy_scene.py) whose depth objects and
+  These run on the repo's NumPy scene (tests/numpy_scene.py) whose depth objects and
   project_image_3d_points are swapped for the reference's own classes loaded above, so every number in the
   fixture was computed by reference code.
 
@@ -35,6 +35,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, REF)  # points3D_utils.py does `from mpsfm.utils.geometry import ...` (importable)
 
 
@@ -148,7 +149,7 @@ def gen_pointcov(rng, out):
 
 def build_reference_scene(seed_scene, seed_maps, n_cams=6, n_pts=300):
     """The repo's NumPy scene with the reference's PriorUtils / Points3DUtils doing the arithmetic."""
-    from mpsfm_amd.sfm.scene import numpy_scene as NS
+    import numpy_scene as NS
     from mpsfm_amd.synthetic import make_scene
 
     RefPrior = load_by_path("ref_priorutils2", "mpsfm/sfm/scene/image/mixins/priorutils.py").PriorUtils

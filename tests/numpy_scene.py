@@ -22,10 +22,10 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from ...synthetic import R_from_quat, quat_from_R
-from ...utils.geometry import project3D_colmap
-from .observations import HipObservationManager
-from .priorutils import PriorUtils
+from mpsfm_amd.synthetic import R_from_quat, quat_from_R
+from mpsfm_amd.utils.geometry import project3D_colmap
+from mpsfm_amd.sfm.scene.observations import HipObservationManager
+from mpsfm_amd.sfm.scene.priorutils import PriorUtils
 
 INVALID_POINT3D = 18446744073709551615  # pycolmap's kInvalidPoint3DId (reference triangulator.py:109)
 

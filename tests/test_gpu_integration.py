@@ -111,7 +111,7 @@ def test_integration_mixin_on_a_scene_matches_oracle():
     with the same gathered inputs."""
     from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
     from numpy_integrable import NumpyIntegrableImage, NumpyNormals
-    from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+    from numpy_scene import scene_from_problem
     from mpsfm_amd.synthetic import make_scene
 
     prob, truth = make_scene(6, 400, True, seed=51)
@@ -229,7 +229,7 @@ def test_int_covs_at_kps_through_the_mixin():
     from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
     from mpsfm_amd.sfm.scene.integration import resize_linear
     from numpy_integrable import NumpyIntegrableImage, NumpyNormals
-    from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+    from numpy_scene import scene_from_problem
     from mpsfm_amd.synthetic import make_scene
 
     prob, truth = make_scene(6, 400, True, seed=52)
@@ -344,7 +344,7 @@ def test_integrate_bundle_batched_on_a_scene():
     from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
     from mpsfm_amd.sfm.scene.integration import integrate_bundle
     from numpy_integrable import NumpyIntegrableImage, NumpyNormals
-    from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+    from numpy_scene import scene_from_problem
     from mpsfm_amd.synthetic import make_scene
 
     def build():

@@ -11,7 +11,7 @@ from mpsfm_amd.dist import shard_problem
 from mpsfm_amd.problem import BAProblem, Tracks
 from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
 from mpsfm_amd.sfm.mapper.triangulator import MpsfmTriangulator, track_quality, triangulate_points
-from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+from numpy_scene import scene_from_problem
 from mpsfm_amd.synthetic import R_from_quat, make_config, make_scene
 from oracle import cpu_oracle as O
 

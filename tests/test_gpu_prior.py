@@ -11,7 +11,7 @@ from backends import OracleBackend
 from conftest import GOLDEN
 from mpsfm_amd import capi
 from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
-from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+from numpy_scene import scene_from_problem
 from mpsfm_amd.sfm.scene.prior_gather import gather_bundle
 from mpsfm_amd.synthetic import make_scene
 from oracle import prior_oracle

@@ -11,7 +11,7 @@ import pytest
 from mapper_replay import MapperReplay
 from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
 from mpsfm_amd.sfm.mapper.triangulator import MpsfmTriangulator, track_quality
-from mpsfm_amd.sfm.scene.numpy_scene import ObservationManager, scene_from_problem
+from numpy_scene import ObservationManager, scene_from_problem
 from mpsfm_amd.sfm.scene.observations import HipObservationManager
 from mpsfm_amd.synthetic import make_scene
 from numpy_integrable import NumpyIntegrableImage, NumpyNormals

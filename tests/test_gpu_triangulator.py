@@ -10,7 +10,7 @@ import pytest
 
 from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
 from mpsfm_amd.sfm.mapper.triangulator import MpsfmTriangulator, track_quality
-from mpsfm_amd.sfm.scene.numpy_scene import INVALID_POINT3D, correspondences_from_problem, scene_from_problem
+from numpy_scene import INVALID_POINT3D, correspondences_from_problem, scene_from_problem
 from mpsfm_amd.synthetic import make_scene
 
 pytestmark = pytest.mark.gpu

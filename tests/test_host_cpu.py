@@ -9,7 +9,7 @@ import pytest
 from conftest import GOLDEN
 from mpsfm_amd.problem import LOSS_CAUCHY, LOSS_SOFT_L1, LOSS_TRIVIAL
 from mpsfm_amd.sfm.mapper.bundle_adjustment import Optimizer
-from mpsfm_amd.sfm.scene.numpy_scene import scene_from_problem
+from numpy_scene import scene_from_problem
 from mpsfm_amd.sfm.scene.priorutils import bilinear_at_kps, fit_robust_gaussian_mad
 from mpsfm_amd.synthetic import make_scene
 from oracle import cpu_oracle as O

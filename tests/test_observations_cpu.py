@@ -6,7 +6,7 @@ import copy
 
 import numpy as np
 
-from mpsfm_amd.sfm.scene.numpy_scene import INVALID_POINT3D, ObservationManager, scene_from_problem
+from numpy_scene import INVALID_POINT3D, ObservationManager, scene_from_problem
 from mpsfm_amd.sfm.scene.observations import HipObservationManager, reprojection_decisions
 from mpsfm_amd.synthetic import make_scene
 from oracle import cpu_oracle as O
