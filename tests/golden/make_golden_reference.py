@@ -266,6 +266,163 @@ def gen_points3d_utils(rng, out):
     out.update(lp_q=q, lp_rot=r.rotate_covs(out["lp_cov"], R))
 
 
+def load_reference_integration():
+    """The reference's Integration class (mpsfm/sfm/scene/image/integration.py:18-29, 82-680) without its module
+    header: the file imports cv2 and cholespy at the top (both absent here), but IntVars / Integration use them
+    only in the down-scaled branches and in IntegrationUncertainty.  The two classes are compiled from the AST
+    into a namespace that holds what the module header would have bound: the NumPy/SciPy matrix library of the
+    reference's own (importable) mpsfm/utils/integration.py:setup_matrix_library("cpu"), its move_* / sigmoid and
+    CameraIntData of mpsfm/sfm/scene/camera.py.  SciPy's cg is wrapped only to COUNT its iterations."""
+    import time
+
+    import torch
+    from tqdm import tqdm, trange
+
+    from mpsfm.sfm.scene.camera import CameraIntData  # reference, importable
+    from mpsfm.utils import integration as ref_ui  # reference, importable
+
+    cp, csr_matrix, cg, identity, diags, sp = ref_ui.setup_matrix_library(device="cpu")
+    counts = []
+
+    def cg_counting(A, b, x0=None, M=None, maxiter=None, rtol=1e-5, callback=None):
+        n = [0]
+
+        def cb(_x):
+            n[0] += 1
+
+        out = cg(A, b, x0=x0, M=M, maxiter=maxiter, rtol=rtol, callback=cb)
+        counts.append(n[0])
+        return out
+
+    assert "rtol" in cg_counting.__code__.co_varnames  # the reference picks the keyword by this test (:463)
+    rel = "mpsfm/sfm/scene/image/integration.py"
+    tree = ast.parse(open(os.path.join(REF, rel)).read())
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("IntVars", "Integration")]
+    for c in body:
+        for n in c.body:
+            if isinstance(n, ast.FunctionDef):
+                n.returns = None
+    mod = ast.Module(body=body, type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = dict(np=np, torch=torch, time=time, tqdm=tqdm, trange=trange, cp=cp, csr_matrix=csr_matrix, cg=cg_counting,
+              identity=identity, diags=diags, sp=sp, device_g="cpu", CameraIntData=CameraIntData, move_left=ref_ui.move_left,
+              move_right=ref_ui.move_right, move_top=ref_ui.move_top, move_bottom=ref_ui.move_bottom, sigmoid=ref_ui.sigmoid)
+    exec(compile(mod, rel, "exec"), ns)
+    return ns["Integration"], CameraIntData, counts
+
+
+REFERENCE_IMAGE_CONF = dict(  # mpsfm/sfm/scene/image/base.py:30-55
+    verbose=0, large_number=1e6, max_iter=10, tol=5e-2, step_size=1, cg_max_iter=5000, cg_tol=1e-3, lambda1=1, lambda2=1, k=1,
+    depth_magnitude_multiplier=1, normals_magnitude_multiplier=1, cov_ignore_depth=True, downscale_factor=2, downscaled=True,
+    scale_filter=True, scale_filter_factor=1.5, robust_triangles=2, ignore_depths=True)
+
+
+def gen_integration(out):
+    """Row f1 / f4: full runs of the reference's own `_integrate` (IRLS + SciPy cg) and `calculate_hessian` on
+    synthetic maps; per-IRLS energies, CG iteration counts, the integrated map, the cached weights, the skip
+    decision of a second call, a changed-conf run, a run that aborts on rising energy."""
+    from mpsfm_amd.synthetic_maps import make_maps
+
+    Integration, CameraIntData, counts = load_reference_integration()
+
+    class Rec(Integration):  # records what calc_energy returns; nothing else is changed
+        def calc_energy(self, *a, **k):
+            e = Integration.calc_energy(self, *a, **k)
+            self.energy_log.append(float(e))
+            return e
+
+        def _prepare_integration_variables(self):  # the prepared tensors (no scene object here)
+            return dict(self.prepared), True
+
+    def image(maps, **conf):
+        im = Rec()
+        H, W = maps["depth_prior"].shape
+        c = dict(REFERENCE_IMAGE_CONF)
+        c.update(conf)
+        im.conf = types.SimpleNamespace(**c)
+        im.camera = CameraIntData(H, W)
+        im.depth = types.SimpleNamespace(data_prior=maps["depth_prior"].copy(), uncertainty=maps["depth_uncertainty"].copy(),
+                                         valid=maps["valid"].astype(bool).copy(), data=maps["depth_init"].copy())
+        im.normals = types.SimpleNamespace(data=maps["normals"].copy(), uncertainty=maps["normals_uncertainty"].copy())
+        im.log = lambda *a, **k: None
+        im.energy_log = []
+        im.prepared = dict(depth3d=maps["depth3d"].copy(), zvars3d=maps["zvars3d"].copy(), kps=maps["kps"].copy(), K=list(maps["K"]))
+        return im
+
+    def run(im, maps):
+        del counts[:]
+        im.energy_log = []
+        changed = im._integrate(maps["depth3d"].copy(), maps["zvars3d"].copy(), maps["kps"].copy(), list(maps["K"]))
+        return bool(changed), np.array(im.energy_log), np.array(counts, np.int64)
+
+    cases = {"a": dict(H=24, W=32, seed=7, n_sparse=25), "b": dict(H=64, W=48, seed=11, n_sparse=90),
+             "c": dict(H=40, W=40, seed=3, n_sparse=0)}
+    rng = np.random.default_rng(99)
+    for tag, kw in cases.items():
+        maps = make_maps(**kw)
+        if tag == "b":  # duplicate sparse pixels (NumPy's last-write-wins in A and b), a point outside the scale filter
+            maps["kps"][5] = maps["kps"][4]
+            maps["kps"][17] = maps["kps"][4]
+            maps["depth3d"][9] *= 1.7
+            maps["depth_uncertainty"] = maps["depth_uncertainty"] * rng.uniform(0.3, 3.0, maps["depth_uncertainty"].shape)
+        for k in ("depth_prior", "depth_uncertainty", "valid", "normals", "depth_init", "kps", "depth3d", "zvars3d"):
+            out[f"int_{tag}_{k}"] = np.asarray(maps[k])
+        out[f"int_{tag}_normals_var"] = np.stack([maps["normals_uncertainty"][..., i, i] for i in range(3)], -1)  # diagonal input
+        out[f"int_{tag}_K"] = np.array(maps["K"], np.float64)
+        im = image(maps)
+        changed, en, its = run(im, maps)
+        assert changed
+        out.update({f"int_{tag}_energies": en, f"int_{tag}_cg_iters": its, f"int_{tag}_out_depth": im.depth.data.copy(),
+                    f"int_{tag}_wu": np.asarray(im.wu), f"int_{tag}_wv": np.asarray(im.wv), f"int_{tag}_energy_old": float(im.energy_old)})
+        # second call on the integrated map with the cached state: energy unchanged -> skipped (:430-434)
+        changed2, en2, its2 = run(im, maps)
+        out.update({f"int_{tag}_second_changed": changed2, f"int_{tag}_second_energies": en2, f"int_{tag}_second_cg_iters": its2})
+        # third call after the sparse depths moved by 40 %: refined again from the cached operators / weights
+        maps3 = dict(maps, depth3d=maps["depth3d"] * 1.4)
+        if len(maps["depth3d"]):
+            changed3, en3, its3 = run(im, maps3)
+            out.update({f"int_{tag}_third_changed": changed3, f"int_{tag}_third_energies": en3, f"int_{tag}_third_cg_iters": its3,
+                        f"int_{tag}_third_out_depth": im.depth.data.copy(), f"int_{tag}_third_energy_old": float(im.energy_old)})
+        # the matrix of calculate_hessian at the integrated map (full resolution), both settings: H @ probe vectors + diagonal
+        probes = np.stack([np.ones(maps["depth_prior"].size), np.sin(np.arange(maps["depth_prior"].size) * 0.37)], 1)
+        out[f"int_{tag}_hess_probes"] = probes
+        for ign in (True, False):
+            im.Hessian = None
+            im.calculate_hessian(downscaled=False, ignore_depths=ign)
+            Hm = im.Hessian.tocsr()
+            assert abs(Hm - Hm.T).max() == 0
+            out[f"int_{tag}_hess_{'ign' if ign else 'all'}_diag"] = Hm.diagonal()
+            out[f"int_{tag}_hess_{'ign' if ign else 'all'}_Hp"] = Hm @ probes
+            out[f"int_{tag}_hess_{'ign' if ign else 'all'}_nnz"] = Hm.nnz
+            # what IntegrationUncertainty.solve(...).sum(0) returns for every pixel, (H^-1 1): the REFERENCE'S matrix,
+            # but SciPy's float64 sparse LU in place of cholespy's float32 Cholesky (cholespy is absent)
+            from scipy.sparse.linalg import spsolve
+            out[f"int_{tag}_hess_{'ign' if ign else 'all'}_colsum"] = spsolve(Hm.tocsc(), np.ones(Hm.shape[0]))
+        out[f"int_{tag}_hess_depth"] = im.depth.data.copy()
+        print(tag, "energies", en, "cg", its, "second", changed2, "third", out.get(f"int_{tag}_third_changed"))
+    # changed conf: k, lambda2, tolerances, no scale filter (24x32)
+    maps = make_maps(**cases["a"])
+    conf = dict(k=2.0, lambda2=3.0, lambda1=0.5, tol=1e-2, cg_tol=1e-5, scale_filter=False, max_iter=4)
+    im = image(maps, **conf)
+    changed, en, its = run(im, maps)
+    out.update(int_conf_energies=en, int_conf_cg_iters=its, int_conf_changed=changed, int_conf_out_depth=im.depth.data.copy())
+    print("conf", en, its, changed)
+    # a run the reference aborts ("Energy increased", :504-508): case c's energy rises slightly at its third IRLS step, so a
+    # fresh image whose checkpoint is the map after two steps starts at the lower energy and steps to the higher one
+    # -> returns False, integrated = True, energy_old = energy_0, depth map untouched
+    maps = make_maps(**cases["c"])
+    im0 = image(maps, max_iter=2)
+    run(im0, maps)
+    maps_ab = dict(maps, depth_init=im0.depth.data.copy())
+    im = image(maps_ab)
+    changed, en, its = run(im, maps_ab)
+    assert not changed and im.integrated
+    out.update(int_abort_depth_init=maps_ab["depth_init"], int_abort_changed=changed, int_abort_energies=en, int_abort_cg_iters=its,
+               int_abort_integrated=bool(im.integrated), int_abort_energy_old=float(im.energy_old),
+               int_abort_depth_after=im.depth.data.copy())
+    print("abort", changed, en, its, im.integrated)
+
+
 if __name__ == "__main__":
     rng = np.random.default_rng(20261004)
     a, b, c = {}, {}, {}
@@ -277,4 +434,7 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "reference_geometry_pointcov.npz"), **b)
     gen_optimizer_numpy_part(c)
     np.savez_compressed(os.path.join(HERE, "reference_optimizer_numpy.npz"), **c)
+    d = {}
+    gen_integration(d)
+    np.savez_compressed(os.path.join(HERE, "reference_integration.npz"), **d)
     print("written:", [f for f in sorted(os.listdir(HERE)) if f.startswith("reference_")])

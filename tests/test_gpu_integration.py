@@ -387,3 +387,88 @@ def test_large_batches_use_the_two_pixel_kernels_and_still_match():
         assert all(abs(a - b) <= 1 for a, b in zip(s1["cg_iters"], s2["cg_iters"]))
         np.testing.assert_allclose(s1["energies"], s2["energies"], rtol=1e-7)
         np.testing.assert_allclose(d1, d2, rtol=1e-6)
+
+
+# ---- against the reference's OWN `_integrate` / `calculate_hessian` (tests/golden/reference_integration.npz) ----------------
+
+@pytest.fixture(scope="module")
+def ri():
+    return np.load(os.path.join(GOLDEN, "reference_integration.npz"))
+
+
+def _cg_close(got, want):
+    return len(got) == len(want) and all(abs(int(a) - int(b)) <= max(1, 0.02 * b) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_hip_integration_equals_reference_full_solve(ri, tag):
+    """f1: `mpsfm_integrate_depth` vs fixtures computed by the reference's own `_integrate` (integration.py:383-520, its
+    CPU branch with SciPy's cg): energies per IRLS step, CG iteration counts, the integrated map, the cached weights, and
+    the skip / refine decisions of the second and third call on the cached state."""
+    from test_reference_fixtures_cpu import reference_integration_maps
+
+    maps = reference_integration_maps(ri, tag)
+    depth, s, wu, wv = _hip(maps)
+    assert s["changed"]
+    np.testing.assert_allclose(s["energies"], ri[f"int_{tag}_energies"], rtol=1e-6)
+    assert _cg_close(s["cg_iters"], ri[f"int_{tag}_cg_iters"]), (s["cg_iters"], ri[f"int_{tag}_cg_iters"])
+    np.testing.assert_allclose(depth, ri[f"int_{tag}_out_depth"], rtol=2e-4)
+    np.testing.assert_allclose(wu, ri[f"int_{tag}_wu"], atol=2e-3)
+    np.testing.assert_allclose(wv, ri[f"int_{tag}_wv"], atol=2e-3)
+    assert s["energy_old"] == pytest.approx(float(ri[f"int_{tag}_energy_old"]), rel=1e-6)
+    # from the REFERENCE's state (its map, its weights, its energy_old): same skip decision and first energy
+    ref_state = dict(integrated=True, energy_old=float(ri[f"int_{tag}_energy_old"]), wu=ri[f"int_{tag}_wu"].copy(), wv=ri[f"int_{tag}_wv"].copy())
+    maps2 = dict(maps, depth_init=ri[f"int_{tag}_out_depth"])
+    d2, s2, *_ = _hip(maps2, **ref_state)
+    assert s2["changed"] == bool(ri[f"int_{tag}_second_changed"]) and d2 is None
+    np.testing.assert_allclose(s2["energies"], ri[f"int_{tag}_second_energies"], rtol=1e-6)
+    if f"int_{tag}_third_changed" in ri.files:
+        maps3 = dict(maps2, depth3d=maps["depth3d"] * 1.4)
+        d3, s3, *_ = _hip(maps3, **ref_state)
+        assert s3["changed"] == bool(ri[f"int_{tag}_third_changed"])
+        np.testing.assert_allclose(s3["energies"], ri[f"int_{tag}_third_energies"], rtol=1e-5)
+        assert _cg_close(s3["cg_iters"], ri[f"int_{tag}_third_cg_iters"])
+        np.testing.assert_allclose(d3, ri[f"int_{tag}_third_out_depth"], rtol=5e-4)
+
+
+def test_hip_integration_equals_reference_conf_and_abort(ri):
+    from test_reference_fixtures_cpu import reference_integration_maps
+
+    maps = reference_integration_maps(ri, "a")
+    conf = dict(k=2.0, lambda2=3.0, lambda1=0.5, tol=1e-2, cg_tol=1e-5, scale_filter=False, max_iter=4)
+    depth, s, *_ = _hip(maps, conf=conf)
+    assert s["changed"] == bool(ri["int_conf_changed"])
+    np.testing.assert_allclose(s["energies"], ri["int_conf_energies"], rtol=1e-6)
+    assert _cg_close(s["cg_iters"], ri["int_conf_cg_iters"])
+    np.testing.assert_allclose(depth, ri["int_conf_out_depth"], rtol=2e-4)
+    # the reference's "Energy increased ... Skipping this frame" exit (:504-508)
+    maps = reference_integration_maps(ri, "c", depth_init=ri["int_abort_depth_init"])
+    depth, s, *_ = _hip(maps)
+    assert s["changed"] is False and depth is None
+    assert s["integrated"] == bool(ri["int_abort_integrated"])
+    assert s["energy_old"] == pytest.approx(float(ri["int_abort_energy_old"]), rel=1e-6)
+    np.testing.assert_allclose(s["energies"], ri["int_abort_energies"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_variances_equal_column_sums_of_the_reference_hessian(ri, tag):
+    """f4: `mpsfm_integration_variances` (one PCG solve H y = 1) vs (H_ref^-1 1) for the matrix built by the reference's
+    own `calculate_hessian` (:522-574), both `ignore_depths` settings; H_ref y = 1 is also checked through the stored
+    products H_ref·probe (H symmetric: y·(H p) = 1·p)."""
+    from test_reference_fixtures_cpu import reference_integration_maps
+
+    maps = reference_integration_maps(ri, tag, depth_init=ri[f"int_{tag}_hess_depth"])
+    nu = maps["normals_uncertainty"]
+    nvar = np.stack([nu[..., 0, 0], nu[..., 1, 1], nu[..., 2, 2]], -1)
+    H, W = maps["depth_prior"].shape
+    xx, yy = np.meshgrid(np.arange(W), np.arange(H))
+    q = np.stack([xx.ravel(), yy.ravel()], 1)
+    for key, sparse in (("ign", False), ("all", True)):
+        v, s = capi.integration_variances(maps["depth_prior"], maps["depth_uncertainty"], maps["valid"], maps["normals"], nvar,
+                                          maps["depth_init"], maps["K"], q, kps=maps["kps"], depth3d=maps["depth3d"],
+                                          zvars3d=maps["zvars3d"], use_sparse=sparse, rtol=1e-12)
+        assert s["converged"]
+        want = ri[f"int_{tag}_hess_{key}_colsum"]
+        np.testing.assert_allclose(v, want, rtol=1e-6, atol=1e-9 * np.abs(want).max())
+        P, HP = ri[f"int_{tag}_hess_probes"], ri[f"int_{tag}_hess_{key}_Hp"]
+        np.testing.assert_allclose(v @ HP, P.sum(0), rtol=1e-6, atol=1e-6 * len(v))
