@@ -307,6 +307,24 @@ int64_t mpsfm_triangulator_num_op_elements(mpsfm_triangulator* h);
 int mpsfm_triangulator_get_op_elements(mpsfm_triangulator* h, int64_t* els);
 int mpsfm_triangulator_stats(mpsfm_triangulator* h, int64_t* batch, int64_t* batch_hits, int64_t* host_estimates);
 
+/* COLMAP's EstimateTriangulation (LORANSAC<TriangulationEstimator, ..., InlierSupportMeasurer, CombinationSampler>, what
+ * IncrementalTriangulator::Create / CompleteImage run per candidate track; reference call sites
+ * mpsfm/sfm/mapper/triangulator.py:88-100, 123) for many independent candidate tracks in ONE launch: one thread per
+ * candidate, at most 64 views each (MPSFM_EUNSUPPORTED beyond).  The engine above uses the same kernel for its batches. */
+typedef struct mpsfm_tri_candidates {
+  int64_t n_candidates;
+  const int64_t* cand_start;          /* [n_candidates+1] CSR into the view arrays                                  */
+  const double* view_cam_from_world;  /* [n_views][3][4] row-major                                                  */
+  const double* view_intr;            /* [n_views][4] PINHOLE fx fy cx cy                                           */
+  const double* view_xy;              /* [n_views][2] pixel measurement                                             */
+  double min_tri_angle;               /* radians (options.min_angle)                                                */
+  double max_error;                   /* radians when residual_type = 0, pixels when 1                              */
+  int32_t residual_type;              /* 0 = ANGULAR_ERROR (Create), 1 = REPROJECTION_ERROR (CompleteImage)         */
+  const int64_t* min_num_trials;      /* [n_candidates] or NULL = C(n,2) up to 15 views, else 0 (Create's rule)     */
+} mpsfm_tri_candidates;
+int mpsfm_tri_estimate_batch(const mpsfm_tri_candidates* c, int32_t device, double* xyz /* [n][3] */, uint8_t* ok /* [n] */,
+                             uint8_t* inlier /* [n_views] */);
+
 /* -- row f3: depth-block selection of Optimizer.__build_problem for a whole bundle in one launch
  *    (mpsfm/sfm/mapper/bundle_adjustment.py:124-161) and the whitened log-depth errors of
  *    update_truncation_multiplier (:295-333).  Per keypoint that has a 3-D point: bilinear samples of the validity

@@ -396,3 +396,30 @@ def integration_variances(depth_prior, depth_uncertainty, valid, normals, normal
                                          C.byref(S)))
     summary = dict(converged=bool(S.changed), cg_iterations=S.cg_iterations_total, ms=S.ms)
     return (out, summary, field) if return_field else (out, summary)
+
+
+class CTriCandidates(C.Structure):
+    _fields_ = [("n_candidates", C.c_int64), ("cand_start", C.c_void_p), ("view_cam_from_world", C.c_void_p), ("view_intr", C.c_void_p),
+                ("view_xy", C.c_void_p), ("min_tri_angle", C.c_double), ("max_error", C.c_double), ("residual_type", C.c_int32),
+                ("min_num_trials", C.c_void_p)]
+
+
+def tri_estimate_batch(cand_start, view_cam_from_world, view_intr, view_xy, min_tri_angle, max_error, residual_type=0,
+                       min_num_trials=None, device=0):
+    """mpsfm_tri_estimate_batch: COLMAP's EstimateTriangulation for many candidate tracks in one launch.
+    Returns (xyz [n,3], ok [n] bool, inlier [n_views] bool)."""
+    cs = np.ascontiguousarray(cand_start, np.int64)
+    n = len(cs) - 1
+    P = np.ascontiguousarray(view_cam_from_world, np.float64).reshape(-1, 12)
+    K = np.ascontiguousarray(view_intr, np.float64).reshape(-1, 4)
+    xy = np.ascontiguousarray(view_xy, np.float64).reshape(-1, 2)
+    if not (len(P) == len(K) == len(xy) == (int(cs[-1]) if n >= 0 and len(cs) else 0)):
+        raise ValueError("view arrays do not match cand_start")
+    mt = None if min_num_trials is None else np.ascontiguousarray(min_num_trials, np.int64)
+    c = CTriCandidates(n, cs.ctypes.data, P.ctypes.data, K.ctypes.data, xy.ctypes.data, float(min_tri_angle), float(max_error),
+                       int(residual_type), None if mt is None else mt.ctypes.data)
+    xyz, ok, inl = np.zeros((max(n, 0), 3)), np.zeros(max(n, 0), np.uint8), np.zeros(len(P), np.uint8)
+    L = lib()
+    L.mpsfm_tri_estimate_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.mpsfm_tri_estimate_batch(C.byref(c), device, xyz.ctypes.data, ok.ctypes.data, inl.ctypes.data))
+    return xyz, ok.astype(bool), inl.astype(bool)

@@ -50,6 +50,8 @@ struct TriView {
   double P[12];
   double C[3];
   double xn[2];
+  double xy[2];  // the pixel measurement and the PINHOLE intrinsics: the reprojection residual of CompleteImage needs them
+  double K[4];
 };
 
 __host__ __device__ inline void tri_make_view(const double* R, const double* t, const double* K, const double* xy, TriView& v) {
@@ -57,6 +59,8 @@ __host__ __device__ inline void tri_make_view(const double* R, const double* t, 
   for (int k = 0; k < 3; ++k) v.C[k] = -(R[k] * t[0] + R[3 + k] * t[1] + R[6 + k] * t[2]);
   v.xn[0] = (xy[0] - K[2]) / K[0];
   v.xn[1] = (xy[1] - K[3]) / K[1];
+  v.xy[0] = xy[0]; v.xy[1] = xy[1];
+  for (int k = 0; k < 4; ++k) v.K[k] = K[k];
 }
 
 __host__ __device__ inline double tri_depth(const double* P, const double* X) { return P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11]; }
@@ -125,14 +129,19 @@ __host__ __device__ inline void tri_multi_accumulate(const TriView& w, double A[
     for (int j = 0; j < 4; ++j) A[i][j] += term[0][i] * term[0][j] + term[1][i] * term[1][j] + term[2][i] * term[2][j];
 }
 
-constexpr int kTriMaxViews = 64;  // longest candidate track the RANSAC below handles in one go
+constexpr int kTriMaxViews = 64;  // longest candidate track the GPU batch takes (fixed scratch per thread); longer ones are
+                                  // estimated on the host with the same function and heap scratch (tri_ransac_scratch)
+
+enum { TRI_RESIDUAL_ANGULAR = 0, TRI_RESIDUAL_REPROJECTION = 1 };  // TriangulationEstimator::ResidualType
 
 struct TriRansacOptions {
   double min_tri_angle;   // radians
-  double max_error;       // radians (angular residual)
+  double max_error;       // radians (angular residual: Create) or pixels (reprojection residual: CompleteImage)
   double confidence;      // 0.9999
   int64_t max_num_trials; // 10000
-  int64_t min_num_trials; // C(n, 2) for n <= 15 (exhaustive), else 0
+  int64_t min_num_trials; // C(n, 2) for n <= 15 (exhaustive), else 0 (CompleteImage: what the previous short track left)
+  int32_t residual_type;  // TRI_RESIDUAL_*
+  int32_t pad;
 };
 
 // TriangulationEstimator::Estimate for the views listed in idx[0..m): fills X, returns false when no model
@@ -159,11 +168,16 @@ struct TriSupport { int num_inliers; double residual_sum; };
 __host__ __device__ inline bool tri_better(const TriSupport& l, const TriSupport& r) {
   return l.num_inliers > r.num_inliers || (l.num_inliers == r.num_inliers && l.residual_sum < r.residual_sum);
 }
-__host__ __device__ inline TriSupport tri_support(const TriView* views, int n, const double* X, double max_residual, double* res) {
+// TriangulationEstimator::Residuals for one view: squared angular error (radians^2) or squared reprojection error (px^2)
+__host__ __device__ inline double tri_residual(const TriView& v, const double* X, int residual_type) {
+  if (residual_type == TRI_RESIDUAL_REPROJECTION) return tri_sq_reproj_error(v.xy, X, v.P, v.K);
+  const double e = tri_angular_error(v.xn, X, v.P);
+  return e * e;
+}
+__host__ __device__ inline TriSupport tri_support(const TriView* views, int n, const double* X, double max_residual, int residual_type, double* res) {
   TriSupport s{0, 0.0};
   for (int i = 0; i < n; ++i) {
-    const double e = tri_angular_error(views[i].xn, X, views[i].P);
-    res[i] = e * e;
+    res[i] = tri_residual(views[i], X, residual_type);
     if (res[i] <= max_residual) { s.num_inliers++; s.residual_sum += res[i]; }
   }
   return s;
@@ -180,11 +194,13 @@ __host__ __device__ inline int64_t tri_num_trials(int num_inliers, int n, double
 
 // EstimateTriangulation over n views: LORANSAC with lexicographic pair sampling (CombinationSampler), local
 // optimisation on the inlier set (up to 10 rounds while it grows), inlier-count support with the residual sum as
-// tie-break.  Returns true on success with X and the inlier mask (bit i of mask[i / 64]).
-__host__ __device__ inline bool tri_ransac(const TriView* views, int n, const TriRansacOptions& o, double* X, uint64_t* mask_out) {
-  if (n < 2 || n > kTriMaxViews) return false;
+// tie-break.  Returns true on success with X and the inlier mask (bit i of mask[i / 64], (n + 63) / 64 words).
+// Scratch: res, best_local_res [n] doubles, idx [n] ints.
+__host__ __device__ inline bool tri_ransac_scratch(const TriView* views, int n, const TriRansacOptions& o, double* X, uint64_t* mask_out,
+                                                   double* res, double* best_local_res, int* idx) {
+  if (n < 2) return false;
   const double max_residual = o.max_error * o.max_error;
-  double res[kTriMaxViews], best_local_res[kTriMaxViews];
+  const int rt = o.residual_type;
   TriSupport best{0, DBL_MAX};
   double bestX[3] = {0, 0, 0};
   const int64_t all_pairs = (int64_t)n * (n - 1) / 2;
@@ -198,17 +214,17 @@ __host__ __device__ inline bool tri_ransac(const TriView* views, int n, const Tr
     if (++b == n) { ++a; b = a + 1; }
     double Xs[3];
     if (!tri_estimate(views, pair, 2, o.min_tri_angle, Xs)) continue;  // no model: LORANSAC tests its stop rule per model only
-    const TriSupport sup = tri_support(views, n, Xs, max_residual, res);
+    const TriSupport sup = tri_support(views, n, Xs, max_residual, rt, res);
     if (tri_better(sup, best)) {
       best = sup; bestX[0] = Xs[0]; bestX[1] = Xs[1]; bestX[2] = Xs[2];
       if (sup.num_inliers > 2) {
         for (int local = 0; local < 10; ++local) {
-          int idx[kTriMaxViews], m = 0;
+          int m = 0;
           for (int i = 0; i < n; ++i) if (res[i] <= max_residual) idx[m++] = i;
           const int prev = best.num_inliers;
           double Xl[3];
           if (tri_estimate(views, idx, m, o.min_tri_angle, Xl)) {
-            const TriSupport ls = tri_support(views, n, Xl, max_residual, best_local_res);
+            const TriSupport ls = tri_support(views, n, Xl, max_residual, rt, best_local_res);
             if (tri_better(ls, best)) {
               best = ls; bestX[0] = Xl[0]; bestX[1] = Xl[1]; bestX[2] = Xl[2];
               for (int i = 0; i < n; ++i) res[i] = best_local_res[i];  // the inlier set of the next round
@@ -223,12 +239,18 @@ __host__ __device__ inline bool tri_ransac(const TriView* views, int n, const Tr
   }
   if (best.num_inliers < 2) return false;
   X[0] = bestX[0]; X[1] = bestX[1]; X[2] = bestX[2];
-  for (int w = 0; w < (kTriMaxViews + 63) / 64; ++w) mask_out[w] = 0;
-  for (int i = 0; i < n; ++i) {
-    const double e = tri_angular_error(views[i].xn, bestX, views[i].P);
-    if (e * e <= max_residual) mask_out[i / 64] |= (uint64_t)1 << (i % 64);
-  }
+  for (int w = 0; w < (n + 63) / 64; ++w) mask_out[w] = 0;
+  for (int i = 0; i < n; ++i)
+    if (tri_residual(views[i], bestX, rt) <= max_residual) mask_out[i / 64] |= (uint64_t)1 << (i % 64);
   return true;
+}
+
+// the fixed-scratch form of the GPU batch (n <= kTriMaxViews)
+__host__ __device__ inline bool tri_ransac(const TriView* views, int n, const TriRansacOptions& o, double* X, uint64_t* mask_out) {
+  if (n < 2 || n > kTriMaxViews) return false;
+  double res[kTriMaxViews], best_local_res[kTriMaxViews];
+  int idx[kTriMaxViews];
+  return tri_ransac_scratch(views, n, o, X, mask_out, res, best_local_res, idx);
 }
 
 }  // namespace mpsfm

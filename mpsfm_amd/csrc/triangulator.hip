@@ -136,34 +136,71 @@ struct mpsfm_triangulator {
     const int64_t c = corr_kp[(size_t)corr_start[(size_t)kp]];
     return corr_start[(size_t)c + 1] - corr_start[(size_t)c] == 1;
   }
+  // EstimateTriangulationOptions as Create sets them up: angular residual, exhaustive sampling up to 15 observations
   static TriRansacOptions ransac_options(const mpsfm_tri_options& o, size_t n) {
-    TriRansacOptions r;
+    TriRansacOptions r{};
     r.min_tri_angle = o.min_angle * M_PI / 180.0;
     r.max_error = o.create_max_angle_error * M_PI / 180.0;
     r.confidence = 0.9999;
     r.max_num_trials = 10000;
     r.min_num_trials = n <= 15 ? (int64_t)n * ((int64_t)n - 1) / 2 : 0;
+    r.residual_type = TRI_RESIDUAL_ANGULAR;
     return r;
+  }
+  // ... and as CompleteImage does: REPROJECTION_ERROR with complete_max_reproj_error in pixels; ONE options object serves
+  // the whole keypoint loop there, so the exhaustive-sampling floor set for a short track stays in force for the
+  // following longer ones (`sticky`: the value the loop carries, updated here)
+  static TriRansacOptions complete_options(const mpsfm_tri_options& o, size_t n, int64_t& sticky) {
+    TriRansacOptions r{};
+    r.min_tri_angle = o.min_angle * M_PI / 180.0;
+    r.max_error = o.complete_max_reproj_error;
+    r.confidence = 0.9999;
+    r.max_num_trials = 10000;
+    if (n <= 15) sticky = (int64_t)n * ((int64_t)n - 1) / 2;
+    r.min_num_trials = sticky;
+    r.residual_type = TRI_RESIDUAL_REPROJECTION;
+    return r;
+  }
+  static bool same_options(const TriRansacOptions& a, const TriRansacOptions& b) {
+    return a.min_tri_angle == b.min_tri_angle && a.max_error == b.max_error && a.confidence == b.confidence &&
+           a.max_num_trials == b.max_num_trials && a.min_num_trials == b.min_num_trials && a.residual_type == b.residual_type;
+  }
+  // the estimator on the host for any track length (heap scratch); inlier flags per view
+  static bool host_ransac(const std::vector<TriView>& views, const TriRansacOptions& opt, double* X, std::vector<uint8_t>& inl) {
+    const int n = (int)views.size();
+    std::vector<double> res((size_t)n), res2((size_t)n);
+    std::vector<int> idx((size_t)n);
+    std::vector<uint64_t> m((size_t)(n + 63) / 64 + 1);
+    inl.assign((size_t)n, 0);
+    if (!tri_ransac_scratch(views.data(), n, opt, X, m.data(), res.data(), res2.data(), idx.data())) return false;
+    for (int i = 0; i < n; ++i) inl[(size_t)i] = (uint8_t)(m[(size_t)i / 64] >> (i % 64) & 1);
+    return true;
   }
 
   // ---- the batch: candidate sets estimated on the GPU, looked up at commit time ----------------------------------------
   struct Batch {
     std::unordered_map<int64_t, int64_t> of_ref;  // reference keypoint -> candidate index
     std::vector<std::vector<int64_t>> sets;
+    std::vector<TriRansacOptions> opts;  // the estimator options each set was estimated with
     std::vector<TriResult> results;
+    void add(int64_t ref, const std::vector<int64_t>& set, const TriRansacOptions& opt) {
+      of_ref[ref] = (int64_t)sets.size();
+      sets.push_back(set);
+      opts.push_back(opt);
+    }
   };
-  int run_batch(const mpsfm_tri_options& o, Batch& B) {
+  int run_batch(Batch& B) {
     const size_t nc = B.sets.size();
     B.results.assign(nc, TriResult{});
     if (nc == 0) return 0;
     std::vector<TriCand> cands(nc);
     std::vector<TriView> views;
     for (size_t i = 0; i < nc; ++i) {
-      cands[i].v0 = (int64_t)views.size(); cands[i].n = (int32_t)B.sets[i].size(); cands[i].opt = ransac_options(o, B.sets[i].size());
+      cands[i].v0 = (int64_t)views.size(); cands[i].n = (int32_t)B.sets[i].size(); cands[i].opt = B.opts[i];
       for (int64_t kp : B.sets[i]) views.push_back(view(kp));
     }
     n_batch += (int64_t)nc;
-    if (!use_gpu) {  // diagnostics / tests: the same arithmetic on the host
+    if (!use_gpu) {  // MPSFM_TRI_HOST_BATCH=1, a TEST switch: the batch arithmetic on the host, to compare the kernel with
       for (size_t i = 0; i < nc; ++i) {
         uint64_t m[(kTriMaxViews + 63) / 64];
         B.results[i].ok = tri_ransac(views.data() + cands[i].v0, cands[i].n, cands[i].opt, B.results[i].X, m) ? 1 : 0;
@@ -190,26 +227,25 @@ struct mpsfm_triangulator {
     cached_free(d_c); cached_free(d_v); cached_free(d_r);
     return rc;
   }
-  // estimate a candidate set: the batch result when the set is unchanged, else on the spot
-  bool estimate(const mpsfm_tri_options& o, const Batch* B, int64_t ref, const std::vector<int64_t>& set, double* X, uint64_t* mask) {
-    if (set.size() > (size_t)kTriMaxViews) return false;
+  // estimate a candidate set: the batch result when set and options are what the batch ran with, else on the spot (host;
+  // also every set longer than kTriMaxViews, which the batch never takes)
+  bool estimate(const TriRansacOptions& opt, const Batch* B, int64_t ref, const std::vector<int64_t>& set, double* X, std::vector<uint8_t>& inl) {
     if (B) {
       auto it = B->of_ref.find(ref);
-      if (it != B->of_ref.end() && B->sets[(size_t)it->second] == set) {
+      if (it != B->of_ref.end() && B->sets[(size_t)it->second] == set && same_options(B->opts[(size_t)it->second], opt)) {
         const TriResult& r = B->results[(size_t)it->second];
         ++n_batch_hits;
         if (!r.ok) return false;
-        X[0] = r.X[0]; X[1] = r.X[1]; X[2] = r.X[2]; *mask = r.mask;
+        X[0] = r.X[0]; X[1] = r.X[1]; X[2] = r.X[2];
+        inl.assign(set.size(), 0);
+        for (size_t i = 0; i < set.size(); ++i) inl[i] = (uint8_t)(r.mask >> i & 1);
         return true;
       }
     }
     ++n_host_estimates;
     std::vector<TriView> views;
     for (int64_t kp : set) views.push_back(view(kp));
-    uint64_t m[(kTriMaxViews + 63) / 64];
-    if (!tri_ransac(views.data(), (int)set.size(), ransac_options(o, set.size()), X, m)) return false;
-    *mask = m[0];
-    return true;
+    return host_ransac(views, opt, X, inl);
   }
 
   // ---- Create / Continue (incremental_triangulator.cc) ------------------------------------------------------------------
@@ -218,10 +254,10 @@ struct mpsfm_triangulator {
     for (int64_t kp : corrs_data) if (!has_pt(kp)) set.push_back(kp);
     if (set.size() < 2) return 0;
     if (o.ignore_two_view_tracks && set.size() == 2 && is_two_view_observation(set[0])) return 0;
-    double X[3]; uint64_t mask = 0;
-    if (!estimate(o, B, ref, set, X, &mask)) return 0;
+    double X[3]; std::vector<uint8_t> inl;
+    if (!estimate(ransac_options(o, set.size()), B, ref, set, X, inl)) return 0;
     std::vector<int64_t> els;
-    for (size_t i = 0; i < set.size(); ++i) if (mask >> i & 1) els.push_back(set[i]);
+    for (size_t i = 0; i < set.size(); ++i) if (inl[i]) els.push_back(set[i]);
     add_point(X, els);
     const size_t kMinRecursiveTrackLength = 3;
     if (set.size() - els.size() >= kMinRecursiveTrackLength) return els.size() + create(o, nullptr, ref, set);
@@ -251,12 +287,11 @@ struct mpsfm_triangulator {
       std::vector<int64_t> set;
       for (int64_t c : corrs) if (!has_pt(c)) set.push_back(c);
       if (!has_pt(kp)) set.push_back(kp);
-      if (set.size() < 2 || set.size() > (size_t)kTriMaxViews) continue;
+      if (set.size() < 2 || set.size() > (size_t)kTriMaxViews) continue;  // longer ones: host estimate at commit time
       if (o.ignore_two_view_tracks && set.size() == 2 && is_two_view_observation(set[0])) continue;
-      B.of_ref[kp] = (int64_t)B.sets.size();
-      B.sets.push_back(set);
+      B.add(kp, set, ransac_options(o, set.size()));
     }
-    if (int rc = run_batch(o, B)) return rc;
+    if (int rc = run_batch(B)) return rc;
     for (int64_t kp = kp_start[(size_t)im]; kp < kp_start[(size_t)im + 1]; ++kp) {  // commit in COLMAP's order
       const size_t num_tri = find(kp, corrs);
       if (corrs.empty()) continue;
@@ -278,23 +313,25 @@ struct mpsfm_triangulator {
     if (!registered[(size_t)im]) return 0;
     std::vector<int64_t> corrs;
     Batch B;
+    int64_t sticky = 0;  // predicted course of the loop's min_num_trials (see complete_options)
     for (int64_t kp = kp_start[(size_t)im]; kp < kp_start[(size_t)im + 1]; ++kp) {
       if (has_pt(kp) || (o.ignore_two_view_tracks && is_two_view_observation(kp))) continue;
-      if (find(kp, corrs) || corrs.empty() || corrs.size() + 1 > (size_t)kTriMaxViews) continue;
+      if (find(kp, corrs) || corrs.empty()) continue;
       corrs.push_back(kp);
-      B.of_ref[kp] = (int64_t)B.sets.size();
-      B.sets.push_back(corrs);
+      const TriRansacOptions opt = complete_options(o, corrs.size(), sticky);
+      if (corrs.size() <= (size_t)kTriMaxViews) B.add(kp, corrs, opt);
     }
-    if (int rc = run_batch(o, B)) return rc;
+    if (int rc = run_batch(B)) return rc;
+    sticky = 0;
     for (int64_t kp = kp_start[(size_t)im]; kp < kp_start[(size_t)im + 1]; ++kp) {
       if (has_pt(kp)) { *count += (int64_t)complete(o, kp_pt[(size_t)kp]); continue; }
       if (o.ignore_two_view_tracks && is_two_view_observation(kp)) continue;
       if (find(kp, corrs) || corrs.empty()) continue;
       corrs.push_back(kp);
-      double X[3]; uint64_t mask = 0;
-      if (!estimate(o, &B, kp, corrs, X, &mask)) continue;
+      double X[3]; std::vector<uint8_t> inl;
+      if (!estimate(complete_options(o, corrs.size(), sticky), &B, kp, corrs, X, inl)) continue;
       std::vector<int64_t> els;
-      for (size_t i = 0; i < corrs.size(); ++i) if (mask >> i & 1) els.push_back(corrs[i]);
+      for (size_t i = 0; i < corrs.size(); ++i) if (inl[i]) els.push_back(corrs[i]);
       *count += (int64_t)els.size();
       add_point(X, els);
     }
@@ -380,38 +417,46 @@ struct mpsfm_triangulator {
         S.corrs.emplace_back(kp, c);
       }
     std::sort(order.begin(), order.end());
-    // under-reconstructed pairs, in pair order; candidate two-view tracks of all of them in one batch
-    struct Todo { uint64_t key; };
+    // COLMAP decides pair by pair on the LIVE ratio (num_tri_corrs moves with every Create / Continue of earlier pairs) and
+    // spends a trial only on a pair it works on.  The batch needs its candidates up front: it takes the pairs that are
+    // under-reconstructed NOW (ratios only grow during the call, so this is a superset of what the walk will take).
+    auto eligible = [&](uint64_t key, double ratio) {
+      if (ratio >= o.re_min_ratio) return false;
+      const int i1 = (int)(key >> 32), i2 = (int)(key & 0xffffffffu);
+      if (ignore.count(i1) || ignore.count(i2)) return false;
+      if (!registered[(size_t)i1] || !registered[(size_t)i2]) return false;
+      auto it = re_num_trials.find(key);
+      return !(it != re_num_trials.end() && it->second >= o.re_max_trials);
+    };
+    Batch B;
     std::vector<uint64_t> todo;
     for (uint64_t key : order) {
       const PairStat& S = pairs[key];
-      if ((double)S.tri / (double)S.total >= o.re_min_ratio) continue;
-      const int i1 = (int)(key >> 32), i2 = (int)(key & 0xffffffffu);
-      if (ignore.count(i1) || ignore.count(i2)) continue;
-      if (!registered[(size_t)i1] || !registered[(size_t)i2]) continue;
-      int& trials = re_num_trials[key];
-      if (trials >= o.re_max_trials) continue;
-      trials += 1;
+      if (!eligible(key, (double)S.tri / (double)S.total)) continue;
       todo.push_back(key);
-    }
-    Batch B;
-    for (uint64_t key : todo)
-      for (const auto& pr : pairs[key].corrs)
+      for (const auto& pr : S.corrs)
         if (!has_pt(pr.first) && !has_pt(pr.second)) {
           if (o.ignore_two_view_tracks && is_two_view_observation(pr.first)) continue;
           if (B.of_ref.count(pr.first)) continue;
-          B.of_ref[pr.first] = (int64_t)B.sets.size();
-          B.sets.push_back({pr.first, pr.second});
+          B.add(pr.first, {pr.first, pr.second}, ransac_options(o, 2));
         }
-    if (int rc = run_batch(o, B)) return rc;
-    for (uint64_t key : todo)
-      for (const auto& pr : pairs[key].corrs) {
+    }
+    if (int rc = run_batch(B)) return rc;
+    for (uint64_t key : todo) {
+      const PairStat& S = pairs[key];
+      int64_t tri = 0;  // live num_tri_corrs of the pair
+      for (const auto& pr : S.corrs)
+        if (kp_pt[(size_t)pr.first] >= 0 && kp_pt[(size_t)pr.first] == kp_pt[(size_t)pr.second]) ++tri;
+      if (!eligible(key, (double)tri / (double)S.total)) continue;
+      re_num_trials[key] += 1;
+      for (const auto& pr : S.corrs) {
         const bool h1 = has_pt(pr.first), h2 = has_pt(pr.second);
         if (h1 && h2) continue;
         if (h1 && !h2) *count += (int64_t)continue_(o.re_max_angle_error, pr.second, {pr.first});
         else if (!h1 && h2) *count += (int64_t)continue_(o.re_max_angle_error, pr.first, {pr.second});
         else *count += (int64_t)create(o, &B, pr.first, {pr.first, pr.second});
       }
+    }
     return 0;
   }
 };
@@ -551,6 +596,68 @@ int mpsfm_triangulator_get_op_elements(mpsfm_triangulator* h, int64_t* els) {
   std::copy(h->op_els.begin(), h->op_els.end(), els);
   return 0;
 }
+// EstimateTriangulation of independent candidate tracks in one k_tri_ransac launch (the engine's batch, exposed for callers
+// that hold candidate sets themselves and for the parity tests against oracle/track_graph_oracle.py).
+int mpsfm_tri_estimate_batch(const mpsfm_tri_candidates* c, int32_t device, double* xyz, uint8_t* ok, uint8_t* inlier) {
+  if (!c || c->n_candidates < 0 || (c->n_candidates > 0 && (!c->cand_start || !xyz || !ok))) return gfail(MPSFM_EINVAL, "NULL argument");
+  const int64_t nc = c->n_candidates;
+  const int64_t nv = nc > 0 ? c->cand_start[nc] : 0;
+  if (nv > 0 && (!c->view_cam_from_world || !c->view_intr || !c->view_xy || !inlier)) return gfail(MPSFM_EINVAL, "view arrays are NULL");
+  if (c->residual_type != TRI_RESIDUAL_ANGULAR && c->residual_type != TRI_RESIDUAL_REPROJECTION) return gfail(MPSFM_EINVAL, "unknown residual type");
+  for (int64_t i = 0; i < nc; ++i) {
+    const int64_t n = c->cand_start[i + 1] - c->cand_start[i];
+    if (n < 0) return gfail(MPSFM_EINVAL, "cand_start must be non-decreasing");
+    if (n > kTriMaxViews) return gfail(MPSFM_EUNSUPPORTED, "a candidate track exceeds 64 views (the batch kernel's scratch)");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gfail(MPSFM_ENODEVICE, "no HIP device visible: libmpsfm_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return gfail(MPSFM_EINVAL, "device ordinal out of range");
+  if (device >= kMaxDevices) return gfail(MPSFM_EUNSUPPORTED, "device ordinals beyond 15 are not supported (per-device pools)");
+  if (nc == 0) return 0;
+  std::vector<TriCand> cands((size_t)nc);
+  std::vector<TriView> views((size_t)nv);
+  for (int64_t v = 0; v < nv; ++v) {
+    const double* P = c->view_cam_from_world + 12 * v;
+    const double R[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    const double t[3] = {P[3], P[7], P[11]};
+    tri_make_view(R, t, c->view_intr + 4 * v, c->view_xy + 2 * v, views[(size_t)v]);
+  }
+  for (int64_t i = 0; i < nc; ++i) {
+    const int64_t n = c->cand_start[i + 1] - c->cand_start[i];
+    TriRansacOptions r{};
+    r.min_tri_angle = c->min_tri_angle; r.max_error = c->max_error; r.confidence = 0.9999; r.max_num_trials = 10000;
+    r.min_num_trials = c->min_num_trials ? c->min_num_trials[i] : (n <= 15 ? n * (n - 1) / 2 : 0);
+    r.residual_type = c->residual_type;
+    cands[(size_t)i].v0 = c->cand_start[i]; cands[(size_t)i].n = (int32_t)n; cands[(size_t)i].opt = r;
+  }
+  if (hipSetDevice(device) != hipSuccess) return gfail(MPSFM_EHIP, "hipSetDevice failed");
+  std::vector<TriResult> results((size_t)nc);
+  TriCand* d_c = (TriCand*)cached_malloc(sizeof(TriCand) * (size_t)nc);
+  TriView* d_v = (TriView*)cached_malloc(sizeof(TriView) * (size_t)(nv > 0 ? nv : 1));
+  TriResult* d_r = (TriResult*)cached_malloc(sizeof(TriResult) * (size_t)nc);
+  int rc = 0;
+  if (!d_c || !d_v || !d_r) rc = gfail(MPSFM_ENOMEM, "hipMalloc failed");
+  if (!rc) rc = staged_upload(d_c, cands.data(), sizeof(TriCand) * (size_t)nc);
+  if (!rc && nv > 0) rc = staged_upload(d_v, views.data(), sizeof(TriView) * (size_t)nv);
+  if (!rc) rc = staged_drain();
+  hipStream_t st = nullptr;
+  if (!rc && pooled_stream(&st) != hipSuccess) rc = gfail(MPSFM_EHIP, "hipStreamCreate failed");
+  if (!rc) {
+    hipLaunchKernelGGL(k_tri_ransac, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, st, d_c, d_v, (int)nc, d_r);
+    if (hipMemcpyAsync(results.data(), d_r, sizeof(TriResult) * (size_t)nc, hipMemcpyDeviceToHost, st) != hipSuccess) rc = gfail(MPSFM_EHIP, "reading the RANSAC batch back failed");
+  }
+  if (st) { (void)hipStreamSynchronize(st); release_stream(st); }
+  cached_free(d_c); cached_free(d_v); cached_free(d_r);
+  if (rc) return rc;
+  for (int64_t i = 0; i < nc; ++i) {
+    const TriResult& r = results[(size_t)i];
+    ok[i] = (uint8_t)r.ok;
+    for (int k = 0; k < 3; ++k) xyz[3 * i + k] = r.ok ? r.X[k] : 0.0;
+    for (int64_t v = c->cand_start[i]; v < c->cand_start[i + 1]; ++v) inlier[v] = r.ok ? (uint8_t)(r.mask >> (v - c->cand_start[i]) & 1) : 0;
+  }
+  return 0;
+}
+
 int mpsfm_triangulator_stats(mpsfm_triangulator* h, int64_t* batch, int64_t* batch_hits, int64_t* host_estimates) {
   if (int rc = check_engine(h)) return rc;
   if (batch) *batch = h->n_batch;

@@ -63,34 +63,62 @@ def _image_pairs(cg):
     return [tuple(pycolmap.pair_id_to_image_pair(pid)) for pid in cg.num_correspondences_between_all_images()]
 
 
+def graph_arrays(correspondence_graph, mpsfm_rec):
+    """Keypoints and correspondence graph of a scene as the flat arrays of `mpsfm_tri_graph` (include/mpsfm_hip.h)."""
+    image_ids = sorted(mpsfm_rec.images.keys())
+    im_index = {imid: i for i, imid in enumerate(image_ids)}
+    nkp = [len(mpsfm_rec.images[i].points2D) for i in image_ids]
+    kp_start = np.concatenate([[0], np.cumsum(nkp)]).astype(np.int64)
+    kp_xy = np.concatenate([np.asarray(mpsfm_rec.keypoints(i), np.float64).reshape(-1, 2) for i in image_ids]) if sum(nkp) else np.zeros((0, 2))
+    intr = np.array([pinhole_params(mpsfm_rec.rec.cameras[mpsfm_rec.images[i].camera_id]) for i in image_ids], np.float64).reshape(-1, 4)
+    src, dst = [], []
+    for id1, id2 in _image_pairs(correspondence_graph):
+        if id1 not in im_index or id2 not in im_index:
+            continue
+        m = np.asarray(correspondence_graph.find_correspondences_between_images(id1, id2), np.int64).reshape(-1, 2)
+        a, b = kp_start[im_index[id1]] + m[:, 0], kp_start[im_index[id2]] + m[:, 1]
+        src += [a, b]
+        dst += [b, a]
+    n_kp = int(kp_start[-1])
+    if src:
+        src, dst = np.concatenate(src), np.concatenate(dst)
+        order = np.lexsort((dst, src))
+        src, dst = src[order], dst[order]
+    else:
+        src = dst = np.zeros(0, np.int64)
+    return dict(image_ids=image_ids, im_index=im_index, kp_start=kp_start, kp_xy=np.ascontiguousarray(kp_xy), intr=np.ascontiguousarray(intr),
+                corr_start=np.searchsorted(src, np.arange(n_kp + 1)).astype(np.int64), corr_kp=np.ascontiguousarray(dst, np.int64),
+                kp_image=np.repeat(np.arange(len(image_ids)), nkp))
+
+
+def state_arrays(mpsfm_rec, image_ids, kp_start):
+    """The mutable part of a scene as the arrays of `mpsfm_tri_state`; also the scene ids of the listed points."""
+    n_im = len(image_ids)
+    reg = np.zeros(n_im, np.uint8)
+    quat, trans = np.zeros((n_im, 4)), np.zeros((n_im, 3))
+    quat[:, 3] = 1.0
+    kp_pid = np.full(int(kp_start[-1]), -1, np.int64)
+    for i, imid in enumerate(image_ids):
+        im = mpsfm_rec.images[imid]
+        reg[i] = 1 if im.has_pose else 0
+        if im.has_pose:
+            quat[i], trans[i] = im.cam_from_world.rotation.quat, im.cam_from_world.translation
+        idx = np.asarray(im.get_observation_point2D_idxs(), np.int64)
+        if len(idx):
+            kp_pid[kp_start[i] + idx] = np.asarray(im.point3D_ids(idx), dtype=np.uint64).astype(np.int64)
+    point_ids = np.unique(kp_pid[kp_pid >= 0])
+    kp_point = np.where(kp_pid >= 0, np.searchsorted(point_ids, kp_pid), -1).astype(np.int64)
+    xyz = np.asarray(mpsfm_rec.point3D_coordinates(point_ids), np.float64).reshape(-1, 3) if len(point_ids) else np.zeros((0, 3))
+    return dict(registered=reg, cam_quat_xyzw=quat, cam_t=trans, kp_point=kp_point, xyz=np.ascontiguousarray(xyz)), point_ids
+
+
 class HipIncrementalTriangulator:
     def __init__(self, correspondence_graph, mpsfm_rec, device: int = 0):
         L = capi.lib()
         self.rec, self.cg, self.device = mpsfm_rec, correspondence_graph, device
-        self.image_ids = sorted(mpsfm_rec.images.keys())
-        self.im_index = {imid: i for i, imid in enumerate(self.image_ids)}
-        nkp = [len(mpsfm_rec.images[i].points2D) for i in self.image_ids]
-        self.kp_start = np.concatenate([[0], np.cumsum(nkp)]).astype(np.int64)
-        self.kp_xy = np.concatenate([np.asarray(mpsfm_rec.keypoints(i), np.float64).reshape(-1, 2) for i in self.image_ids]) if sum(nkp) else np.zeros((0, 2))
-        self.intr = np.array([pinhole_params(mpsfm_rec.rec.cameras[mpsfm_rec.images[i].camera_id]) for i in self.image_ids], np.float64).reshape(-1, 4)
-        src, dst = [], []
-        for id1, id2 in _image_pairs(correspondence_graph):
-            if id1 not in self.im_index or id2 not in self.im_index:
-                continue
-            m = np.asarray(correspondence_graph.find_correspondences_between_images(id1, id2), np.int64).reshape(-1, 2)
-            a, b = self.kp_start[self.im_index[id1]] + m[:, 0], self.kp_start[self.im_index[id2]] + m[:, 1]
-            src += [a, b]
-            dst += [b, a]
-        n_kp = int(self.kp_start[-1])
-        if src:
-            src, dst = np.concatenate(src), np.concatenate(dst)
-            order = np.lexsort((dst, src))
-            src, dst = src[order], dst[order]
-        else:
-            src = dst = np.zeros(0, np.int64)
-        self.corr_start = np.searchsorted(src, np.arange(n_kp + 1)).astype(np.int64)
-        self.corr_kp = np.ascontiguousarray(dst, np.int64)
-        self.kp_image = np.repeat(np.arange(len(self.image_ids)), nkp)
+        ga = graph_arrays(correspondence_graph, mpsfm_rec)
+        for k, v in ga.items():
+            setattr(self, k, v)
         g = CTriGraph(len(self.image_ids), self.kp_start.ctypes.data, self.kp_xy.ctypes.data, self.intr.ctypes.data,
                       self.corr_start.ctypes.data, self.corr_kp.ctypes.data)
         self._h = C.c_void_p(None)
@@ -125,26 +153,11 @@ class HipIncrementalTriangulator:
 
     # -- state hand-over and replay ------------------------------------------------------------------------------------
     def _sync(self):
-        rec = self.rec
-        n_im = len(self.image_ids)
-        reg = np.zeros(n_im, np.uint8)
-        quat, trans = np.zeros((n_im, 4)), np.zeros((n_im, 3))
-        quat[:, 3] = 1.0
-        kp_pid = np.full(int(self.kp_start[-1]), -1, np.int64)
-        for i, imid in enumerate(self.image_ids):
-            im = rec.images[imid]
-            reg[i] = 1 if im.has_pose else 0
-            if im.has_pose:
-                quat[i], trans[i] = im.cam_from_world.rotation.quat, im.cam_from_world.translation
-            idx = np.asarray(im.get_observation_point2D_idxs(), np.int64)
-            if len(idx):
-                kp_pid[self.kp_start[i] + idx] = np.asarray(im.point3D_ids(idx), dtype=np.uint64).astype(np.int64)
-        self._point_ids = np.unique(kp_pid[kp_pid >= 0])
-        kp_point = np.where(kp_pid >= 0, np.searchsorted(self._point_ids, kp_pid), -1).astype(np.int64)
-        xyz = np.asarray(rec.point3D_coordinates(self._point_ids), np.float64).reshape(-1, 3) if len(self._point_ids) else np.zeros((0, 3))
-        xyz = np.ascontiguousarray(xyz)
-        st = CTriState(reg.ctypes.data, quat.ctypes.data, trans.ctypes.data, kp_point.ctypes.data, len(self._point_ids), xyz.ctypes.data)
-        capi._check(capi.lib().mpsfm_triangulator_set_state(self._h, C.byref(st)))
+        st, self._point_ids = state_arrays(self.rec, self.image_ids, self.kp_start)
+        self.last_state = st  # what the engine was handed
+        cst = CTriState(st["registered"].ctypes.data, st["cam_quat_xyzw"].ctypes.data, st["cam_t"].ctypes.data, st["kp_point"].ctypes.data,
+                        len(self._point_ids), st["xyz"].ctypes.data)
+        capi._check(capi.lib().mpsfm_triangulator_set_state(self._h, C.byref(cst)))
         self._scene_id = {i: int(p) for i, p in enumerate(self._point_ids)}  # engine point -> scene point id
 
     def _track_types(self):
