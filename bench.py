@@ -5,8 +5,12 @@ One step = one full BA solve (Ceres-default LM until convergence) of the synthet
 150k-landmark scene with reprojection + log-depth prior blocks (BASELINE config "C3"), starting
 from the same perturbed state every step (device-to-device reset, inside the timed region).
 The problem is resident in HBM before the timed region starts.  With N > 1 ranks the landmarks
-are sharded (each rank owns 150k landmarks around the same 200 cameras: weak scaling) and the
-ranks exchange the reduced camera system with an RCCL all-reduce every LM iteration.
+are sharded and the ranks exchange the reduced camera system with an RCCL all-reduce every LM
+iteration.  `--scaling weak` (default): each rank owns the configuration's landmark count around
+the same cameras (N x 150 k landmarks at C3).  `--scaling strong`: the configuration's OWN landmarks
+are cut into N contiguous ranges balanced by residual blocks (`mpsfm_amd.dist.shard_problem`) — the form
+BASELINE config 4 names ("1000 images / 800k points ... landmark-sharded across 8 GPUs":
+`--config C4 --gpus 8 --scaling strong`); the replicated dense solve bounds it.
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,6 +35,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("MPSFM_BENCH_SCALING", "weak"),
+                    help="weak: every rank draws the configuration's landmark count; strong: the configuration's landmarks are sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--kernel-reps", type=int, default=20, help="launches used to time the sweep / dense kernels")
@@ -71,7 +77,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    prob, _ = make_config(args.config, seed=0, shard=rank)
+    if args.scaling == "strong" and world > 1:
+        from mpsfm_amd.dist import shard_problem
+
+        full, _ = make_config(args.config, seed=0, shard=0)  # the same problem on every rank, cut by landmark range
+        prob, (lm_lo, lm_hi) = shard_problem(full, rank, world)
+        del full
+    else:
+        prob, _ = make_config(args.config, seed=0, shard=rank)
     opts = capi.default_options(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     collective = None
     if dist is not None:
@@ -183,14 +196,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.config}: {CONFIGS[args.config][0]} cameras, {CONFIGS[args.config][1]} landmarks per rank, "
-                        f"{prob.n_obs} reprojection + {prob.n_dobs} log-depth blocks per rank, SoftL1/Cauchy, Ceres-default LM",
-            "parallelism": (f"landmark-sharded x{world}, {collective}" if collective else f"landmark-sharded x{world}") if (world > 1 or collective) else "single GPU",
+            "workload": (f"{args.config}: {CONFIGS[args.config][0]} cameras, {CONFIGS[args.config][1]} landmarks per rank, "
+                         f"{prob.n_obs} reprojection + {prob.n_dobs} log-depth blocks per rank, SoftL1/Cauchy, Ceres-default LM"
+                         if not (args.scaling == "strong" and world > 1) else
+                         f"{args.config}: {CONFIGS[args.config][0]} cameras, {CONFIGS[args.config][1]} landmarks IN TOTAL cut into {world} landmark "
+                         f"ranges (rank 0: {prob.n_pts} landmarks, {prob.n_obs} reprojection + {prob.n_dobs} log-depth blocks), SoftL1/Cauchy, Ceres-default LM"),
+            "parallelism": ((f"landmark-sharded x{world} ({args.scaling}: " + ("the configuration's landmarks split" if args.scaling == "strong" else "the configuration's landmark count per rank")
+                             + (f"), {collective}" if collective else ")")) if (world > 1 or collective) else "single GPU"),
             "residual_blocks_total": last["num_residual_blocks"],
         },
         "solve": {

@@ -691,6 +691,48 @@ static void parallel_ranges(int64_t n, int64_t min_grain, F&& f) {
 
 // Build the re-ordered, chunked record tables and upload everything.
 // the tables of the level-scheduled factorisation (h->plan) to the device
+// The camera graph of a landmark-sharded run is the UNION over the ranks, and the exchange can only SUM doubles: every rank
+// packs its adjacency bits as indicator digits in base (world + 1), E digits per double (E chosen so that a sum of `world`
+// such numbers stays below 2^53, i.e. exact), the packed vectors are summed, and a digit > 0 means "some rank has the edge".
+static int graph_digits(int world) {
+  int E = 1;
+  double cap = 9007199254740992.0 / (world + 1);
+  while (cap >= (world + 1) && E < 16) { cap /= (world + 1); ++E; }
+  return E;
+}
+static void pack_graph(const CamGraph& graph, int world, std::vector<double>& packed) {
+  const int E = graph_digits(world), n = graph.n;
+  const int64_t nbits = (int64_t)n * n;
+  packed.assign((size_t)((nbits + E - 1) / E), 0.0);
+  double pw[16];
+  pw[0] = 1.0;
+  for (int e = 1; e < 16; ++e) pw[e] = pw[e - 1] * (double)(world + 1);
+  for (int a = 0; a < n; ++a) {
+    const uint64_t* row = graph.row(a);
+    for (int w = 0; w < graph.words; ++w) {
+      uint64_t m = row[w];
+      while (m) {
+        const int64_t q = (int64_t)a * n + (w * 64 + __builtin_ctzll(m));
+        m &= m - 1;
+        packed[(size_t)(q / E)] += pw[q % E];
+      }
+    }
+  }
+}
+static void unpack_graph(const std::vector<double>& packed, int world, CamGraph& graph) {
+  const int E = graph_digits(world), n = graph.n;
+  const int64_t nbits = (int64_t)n * n;
+  for (size_t w = 0; w < packed.size(); ++w) {
+    double v = packed[w];
+    for (int e = 0; e < E && v > 0.0; ++e) {
+      const double d = std::fmod(v, (double)(world + 1));
+      v = std::floor(v / (world + 1));
+      const int64_t q = (int64_t)w * E + e;
+      if (d > 0.0 && q < nbits) graph.set((int)(q / n), (int)(q % n));
+    }
+  }
+}
+
 static int upload_plan(mpsfm_ba_handle* h, int64_t nblk) {
   const CholPlan& PL = h->plan;
   int rc2 = 0;
@@ -831,39 +873,15 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     });
     for (const auto& B : gb) for (size_t w = 0; w < B.size(); ++w) graph.bits[w] |= B[w];
     if (sharded(h)) {
-      // union over the ranks through the sum exchange: E indicator digits per double in base (world + 1)
-      // the number of ranks from the exchange itself (a hook may come without world_size)
+      // union over the ranks through the sum exchange (pack_graph / unpack_graph); the number of ranks comes from the
+      // exchange itself (a hook may come without world_size)
       double ones = 1.0;
       if (int rc = allreduce_host(h, &ones, 1)) return rc;
       const int world = std::max((int)std::llround(ones), 1);
-      int E = 1;
-      { double cap = 9007199254740992.0 / (world + 1); while (cap >= (world + 1) && E < 16) { cap /= (world + 1); ++E; } }
-      const int64_t nbits = (int64_t)ncv_real * ncv_real;
-      std::vector<double> packed((size_t)((nbits + E - 1) / E), 0.0);
-      double pw[16];
-      pw[0] = 1.0;
-      for (int e = 1; e < 16; ++e) pw[e] = pw[e - 1] * (double)(world + 1);
-      for (int a = 0; a < ncv_real; ++a) {
-        const uint64_t* row = graph.row(a);
-        for (int w = 0; w < graph.words; ++w) {
-          uint64_t m = row[w];
-          while (m) {
-            const int64_t q = (int64_t)a * ncv_real + (w * 64 + __builtin_ctzll(m));
-            m &= m - 1;
-            packed[(size_t)(q / E)] += pw[q % E];
-          }
-        }
-      }
+      std::vector<double> packed;
+      pack_graph(graph, world, packed);
       if (int rc = allreduce_host(h, packed.data(), (int64_t)packed.size())) return rc;
-      for (size_t w = 0; w < packed.size(); ++w) {
-        double v = packed[w];
-        for (int e = 0; e < E && v > 0.0; ++e) {
-          const double d = std::fmod(v, (double)(world + 1));
-          v = std::floor(v / (world + 1));
-          const int64_t q = (int64_t)w * E + e;
-          if (d > 0.0 && q < nbits) graph.set((int)(q / ncv_real), (int)(q % ncv_real));
-        }
-      }
+      unpack_graph(packed, world, graph);
     }
     lap("camera graph");
     int forced_depth = -2;
@@ -1830,6 +1848,30 @@ extern "C" int64_t mpsfm_debug_run_parts(int32_t nparts, int32_t reps) {
     for (auto& x : hits) bad += x.load() == 1 ? 0 : 1;
   }
   return bad;
+}
+
+// Test hook (tests/test_dist_cpu.py; no device involved): the camera-graph union of a landmark-sharded run as the ranks
+// compute it — `world` adjacency matrices (n x n bytes each) packed per rank, summed like the all-reduce does, unpacked
+// into `out` (n x n bytes).  Returns the digits per double used.
+extern "C" int mpsfm_debug_graph_union(const uint8_t* adj, int32_t world, int32_t n, uint8_t* out) {
+  std::vector<double> sum;
+  for (int r = 0; r < world; ++r) {
+    mpsfm::CamGraph g;
+    g.init(n);
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b)
+        if (adj[((size_t)r * n + a) * n + b]) g.set(a, b);
+    std::vector<double> packed;
+    mpsfm::pack_graph(g, world, packed);
+    if (sum.empty()) sum.assign(packed.size(), 0.0);
+    for (size_t i = 0; i < packed.size(); ++i) sum[i] += packed[i];
+  }
+  mpsfm::CamGraph u;
+  u.init(n);
+  mpsfm::unpack_graph(sum, world, u);
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b) out[(size_t)a * n + b] = u.get(a, b) ? 1 : 0;
+  return mpsfm::graph_digits(world);
 }
 
 extern "C" {

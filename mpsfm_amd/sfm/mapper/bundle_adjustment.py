@@ -250,9 +250,8 @@ class Optimizer(BaseClass):
                 mask &= (f & F_SCALE) != 0
             if gross_outliers:
                 mask &= (f & F_GROSS) != 0
-            for k, imid in enumerate(g["images"]):
-                if not mask[g["obs_img"] == k].any():
-                    self.log("No valid points for depth regularizing", level=1)
+            for _ in np.flatnonzero(np.bincount(g["obs_img"][mask], minlength=len(g["images"])) == 0):
+                self.log("No valid points for depth regularizing", level=1)
             cam_idx = np.array([cam_of[i] for i in g["images"]], np.int32)
             dobs_cam = cam_idx[g["obs_img"][mask]]
             dobs_pt = index_in_sorted(self._sorted_point_ids, g["obs_pid"][mask]).astype(np.int32)

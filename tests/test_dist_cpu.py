@@ -71,3 +71,51 @@ def test_two_rank_sharded_solve_matches_single_rank(tmp_path):
         np.testing.assert_allclose(o["cam_t"], ref.cam_t, atol=1e-7)       # replicated cameras agree
         np.testing.assert_allclose(o["pts"], ref.pts[int(o["lo"]):int(o["hi"])], atol=1e-7)
     np.testing.assert_allclose(outs[0]["cam_quat"], outs[1]["cam_quat"], atol=1e-12)
+
+
+def test_strong_scaling_shards_reassemble_to_the_single_rank_problem():
+    """bench.py --scaling strong: the configuration's own landmarks cut into N ranges — every residual block lands in exactly
+    one shard with its values, landmark indices shift by the range start, cameras are replicated."""
+    prob, _ = make_scene(14, 3000, True, seed=9)
+    for world in (2, 4, 8):
+        obs, dobs, pts = [], [], []
+        for rank in range(world):
+            sh, (lo, hi) = shard_problem(prob, rank, world)
+            np.testing.assert_array_equal(sh.cam_quat, prob.cam_quat)
+            np.testing.assert_array_equal(sh.pose_const, prob.pose_const)
+            assert sh.gauge_axis_cam == prob.gauge_axis_cam and sh.depth_loss_type == prob.depth_loss_type
+            assert sh.obs_pt.min() >= 0 and sh.obs_pt.max() < hi - lo
+            obs.append(np.column_stack([sh.obs_cam, sh.obs_pt + lo, sh.obs_xy]))
+            dobs.append(np.column_stack([sh.dobs_cam, sh.dobs_pt + lo, sh.dobs_depth, sh.dobs_magnitude, sh.dobs_param]))
+            pts.append(sh.pts)
+        np.testing.assert_array_equal(np.concatenate(pts), prob.pts)
+        key = lambda a: a[np.lexsort((a[:, 0], a[:, 1]))]
+        np.testing.assert_array_equal(key(np.concatenate(obs)), key(np.column_stack([prob.obs_cam, prob.obs_pt, prob.obs_xy])))
+        np.testing.assert_array_equal(key(np.concatenate(dobs)),
+                                      key(np.column_stack([prob.dobs_cam, prob.dobs_pt, prob.dobs_depth, prob.dobs_magnitude, prob.dobs_param])))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8, 64])
+def test_camera_graph_union_through_the_sum_exchange(world):
+    """What the ranks of a sharded run do at handle creation (ba_solver.hip pack_graph / unpack_graph): adjacency indicators
+    packed as base-(world+1) digits, summed, unpacked — equals the OR of the ranks' graphs, for every world size the summed
+    digits stay exact."""
+    import ctypes as C
+
+    from mpsfm_amd import capi
+
+    L = capi.lib()
+    L.mpsfm_debug_graph_union.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    rng = np.random.default_rng(world)
+    for n in (1, 7, 67, 130):
+        adj = (rng.uniform(size=(world, n, n)) < 0.15).astype(np.uint8)
+        adj = np.maximum(adj, adj.transpose(0, 2, 1))
+        if world > 1:
+            adj[0] = 0                     # a rank without landmarks
+            adj[1][: n // 2, : n // 2] = 1  # ... and one dense corner, every rank's digit set somewhere
+            adj[:, n - 1, n - 1] = 1       # the same edge on EVERY rank: the digit reaches `world`
+        adj = np.ascontiguousarray(adj)
+        out = np.zeros((n, n), np.uint8)
+        E = L.mpsfm_debug_graph_union(adj.ctypes.data, world, n, out.ctypes.data)
+        assert (world + 1) ** E * 1.0 <= 2.0**53 and E >= 1
+        np.testing.assert_array_equal(out, adj.max(0))

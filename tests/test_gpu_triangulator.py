@@ -410,3 +410,28 @@ def test_complete_image_uses_the_reprojection_residual_in_pixels():
         _, ok_p, in_p = capi.tri_estimate_batch(cs, Ps, Ks, x2, 0.0, px_bound, 1)
         assert ok_a[0] and ok_p[0] and in_a[:5].all() and in_p[:5].all()
         assert bool(in_a[5]) == ang_in and bool(in_p[5]) == px_in, (off, in_a, in_p)
+
+
+def test_candidate_tracks_beyond_the_batch_limit_are_estimated_on_the_host_like_the_oracle():
+    """All 72 images registered before the first triangulate_image: every keypoint meets ~70 untriangulated correspondences,
+    more than the 64 views a batch thread holds — those candidates are estimated on the host (same function, heap scratch)
+    and the log still equals the oracle's; beyond 15 views the sampling is not exhaustive (stop rule decides)."""
+    from oracle import track_graph_oracle as TG
+
+    prob, truth = make_scene(72, 40, True, seed=91, perturb=False, outlier_frac=0.05, max_track=72, track_mean=90.0)
+    sc = scene_from_problem(prob, truth, seed=91, with_points=False)
+    cg = correspondences_from_problem(sc, prob, false_matches=30, seed=91)
+    tri = MpsfmTriangulator({"colmap_options": dict(OPTS), "lift_low_parallax": False}, sc, cg)
+    tri._require_engine()
+    eng = tri._triangulator
+    orc = TG.TrackGraphOracle(eng.kp_start, eng.kp_xy, eng.intr, eng.corr_start, eng.corr_kp)
+    ids = sorted(sc.images)
+    assert np.diff(eng.corr_start).max() > 64
+    for imid in ids[:3]:
+        n_g = eng.triangulate_image(tri.options, imid)
+        st = eng.last_state
+        orc.set_state(st["registered"], st["cam_quat_xyzw"], st["cam_t"], st["kp_point"], st["xyz"])
+        assert n_g == orc.triangulate_image(dict(OPTS), eng.im_index[imid])
+        _assert_same_ops(_engine_ops(eng), orc.ops, f"triangulate_image({imid})")
+    assert max(p.track.length() for p in sc.points3D.values()) > 64 and eng.stats()["host_estimates"] > 10
+    check_consistency(sc)
