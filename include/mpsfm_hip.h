@@ -195,9 +195,13 @@ void mpsfm_ba_destroy(mpsfm_ba_handle* h);
 int mpsfm_ba_eval_cost(mpsfm_ba_handle* h, double* cost_reproj, double* cost_depth);
 
 /* One Jacobian/Schur track sweep at the current state with trust-region radius `radius`
- * (no parameter update): the kernel bench.py prices against the HBM roofline.
- * `elapsed_ms` receives the HIP-event time of that kernel alone. */
+ * (no parameter update): the launches bench.py prices against the HBM roofline.
+ * `elapsed_ms` receives the HIP-event time of the whole sweep (dense chunks, reduction of their slabs,
+ * general chunks and long tracks). */
 int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms);
+/* The parts of the last mpsfm_ba_sweep_once: ms = {k_track_sweep_dense, k_reduce_slabs, general + long-track kernels},
+ * info = {dense chunks, general chunks, long tracks, destination parts of the reduction}.  Either pointer may be NULL. */
+int mpsfm_ba_sweep_parts(mpsfm_ba_handle* h, float ms[3], int64_t info[4]);
 /* Download the reduced camera system built by the last sweep: S (n x n, row-major, symmetric)
  * and rhs (n); n = summary.reduced_dim = 6 x variable cameras, rows in the CALLER's camera order
  * (the handle keeps its own slot order, see mpsfm_ba_dense_plan).  Test/diagnostic entry point. */

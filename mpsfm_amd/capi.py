@@ -180,6 +180,14 @@ class BAHandle:
         _check(lib().mpsfm_ba_sweep_once(self._h, radius, C.byref(ms)))
         return ms.value
 
+    def sweep_parts(self) -> dict:
+        """HIP-event times of the parts of the last sweep_once and the chunk counts behind them."""
+        ms, info = (C.c_float * 3)(), (C.c_int64 * 4)()
+        lib().mpsfm_ba_sweep_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(lib().mpsfm_ba_sweep_parts(self._h, ms, info))
+        return dict(dense_ms=ms[0], reduce_ms=ms[1], general_ms=ms[2], dense_chunks=int(info[0]), general_chunks=int(info[1]),
+                    long_tracks=int(info[2]), reduce_parts=int(info[3]))
+
     def dense_solve_once(self) -> float:
         ms = C.c_float(0)
         _check(lib().mpsfm_ba_dense_solve_once(self._h, C.byref(ms)))

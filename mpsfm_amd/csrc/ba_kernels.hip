@@ -10,201 +10,14 @@
 //   k_update_sweep  back-substitution of the landmark steps, model cost change, candidate
 //                   landmarks and the candidate cost in one pass over the same chunks.
 #include "common.h"
+#include "sweep_common.h"
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
 
 namespace mpsfm {
 
-struct RecLin {
-  double Jc[18];  // 3 x 6 (rows 0,1 reprojection, row 2 log-depth), robustified + scaled
-  double Jp[9];   // 3 x 3
-  double r[3];
-  double cost;
-  bool ok;
-};
 
-// residual blocks of one merged record at camera `cam` (table row) and landmark X
-__device__ __forceinline__ void linearize_record(const double* __restrict__ cam, const double* X,
-                                                 const double* psc, uint32_t meta, double u, double v,
-                                                 double d, double m, double a, const LossParams& L,
-                                                 RecLin& o) {
-  double c[24];
-  const double2* c2 = reinterpret_cast<const double2*>(cam);
-#pragma unroll
-  for (int i = 0; i < 11; ++i) { const double2 t = c2[i]; c[2 * i] = t.x; c[2 * i + 1] = t.y; }
-  const double* R = c; const double* t = c + 9; const double* K = c + 12; const double* cs = c + 16;
-  const double Y0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
-  const double Y1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
-  const double Y2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
-  const double Xc = Y0 + t[0], Yc = Y1 + t[1], Zc = Y2 + t[2];
-  const double iz = 1.0 / Zc;
-  o.cost = 0.0;
-  o.ok = true;
-#pragma unroll
-  for (int i = 0; i < 18; ++i) o.Jc[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) o.Jp[i] = 0.0;
-  o.r[0] = o.r[1] = o.r[2] = 0.0;
-  if (meta & kRecHasReproj) {
-    const double r0 = K[0] * Xc * iz + K[2] - u;
-    const double r1 = K[1] * Yc * iz + K[3] - v;
-    double rho0, rho1;
-    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
-    o.cost += 0.5 * L.reproj_mag * rho0;
-    o.ok = o.ok && isfinite(r0) && isfinite(r1);
-    const double w = sqrt(L.reproj_mag * rho1);
-    const double a00 = w * K[0] * iz, a02 = -w * K[0] * Xc * iz * iz;
-    const double a11 = w * K[1] * iz, a12 = -w * K[1] * Yc * iz * iz;
-    o.r[0] = w * r0; o.r[1] = w * r1;
-    o.Jc[0] = a02 * (2 * Y1) * cs[0];
-    o.Jc[1] = (a00 * (2 * Y2) - a02 * (2 * Y0)) * cs[1];
-    o.Jc[2] = -a00 * (2 * Y1) * cs[2];
-    o.Jc[3] = a00 * cs[3];
-    o.Jc[5] = a02 * cs[5];
-    o.Jc[6] = (a12 * (2 * Y1) - a11 * (2 * Y2)) * cs[0];
-    o.Jc[7] = -a12 * (2 * Y0) * cs[1];
-    o.Jc[8] = a11 * (2 * Y0) * cs[2];
-    o.Jc[10] = a11 * cs[4];
-    o.Jc[11] = a12 * cs[5];
-    o.Jp[0] = (a00 * R[0] + a02 * R[6]) * psc[0];
-    o.Jp[1] = (a00 * R[1] + a02 * R[7]) * psc[1];
-    o.Jp[2] = (a00 * R[2] + a02 * R[8]) * psc[2];
-    o.Jp[3] = (a11 * R[3] + a12 * R[6]) * psc[0];
-    o.Jp[4] = (a11 * R[4] + a12 * R[7]) * psc[1];
-    o.Jp[5] = (a11 * R[5] + a12 * R[8]) * psc[2];
-  }
-  if (meta & kRecHasDepth) {
-    if (!(Zc > 0.0)) {
-      o.ok = false;
-    } else {
-      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
-      double rho0, rho1;
-      loss_eval(L.depth_type, a, rd * rd, rho0, rho1);
-      o.cost += 0.5 * m * rho0;
-      const double w = sqrt(m * rho1) * iz;
-      o.r[2] = sqrt(m * rho1) * rd;
-      o.Jc[12] = w * (2 * Y1) * cs[0];
-      o.Jc[13] = -w * (2 * Y0) * cs[1];
-      o.Jc[17] = w * cs[5];
-      o.Jp[6] = w * R[6] * psc[0];
-      o.Jp[7] = w * R[7] * psc[1];
-      o.Jp[8] = w * R[8] * psc[2];
-    }
-  }
-}
-
-// The update sweep's view of a record: rows of Jp, the robustified residuals and mrow = Jc yc, with the camera Jacobian
-// folded into the products (ys = cs .* yc) instead of materialised — 36 registers less at the kernel's pressure peak, which
-// is what held it at four waves per SIMD — and without the loss value (one logarithm less per Cauchy block).
-struct RecUpd {
-  double Jp[9], r[3], mrow[3];
-  bool ok;
-};
-__device__ __forceinline__ void linearize_update(const double* __restrict__ cam, const double* X, const double* psc, uint32_t meta, double u, double v,
-                                                 double d, double m, double a, const LossParams& L, const double* yc, RecUpd& o) {
-  double c[24];
-  const double2* c2 = reinterpret_cast<const double2*>(cam);
-#pragma unroll
-  for (int i = 0; i < 11; ++i) { const double2 t = c2[i]; c[2 * i] = t.x; c[2 * i + 1] = t.y; }
-  const double* R = c; const double* t = c + 9; const double* K = c + 12; const double* cs = c + 16;
-  const double Y0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
-  const double Y1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
-  const double Y2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
-  const double Xc = Y0 + t[0], Yc = Y1 + t[1], Zc = Y2 + t[2];
-  const double iz = 1.0 / Zc;
-  double ys[6] = {0, 0, 0, 0, 0, 0};
-  if (yc) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ys[k] = cs[k] * yc[k];
-  }
-  o.ok = true;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) o.Jp[i] = 0.0;
-  o.r[0] = o.r[1] = o.r[2] = 0.0;
-  o.mrow[0] = o.mrow[1] = o.mrow[2] = 0.0;
-  if (meta & kRecHasReproj) {
-    const double r0 = K[0] * Xc * iz + K[2] - u;
-    const double r1 = K[1] * Yc * iz + K[3] - v;
-    double rho0, rho1;
-    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
-    o.ok = o.ok && isfinite(r0) && isfinite(r1);
-    const double w = sqrt(L.reproj_mag * rho1);
-    const double a00 = w * K[0] * iz, a02 = -w * K[0] * Xc * iz * iz;
-    const double a11 = w * K[1] * iz, a12 = -w * K[1] * Yc * iz * iz;
-    o.r[0] = w * r0; o.r[1] = w * r1;
-    // the rows of Jc as in linearize_record, times ys
-    o.mrow[0] = a02 * (2 * Y1) * ys[0] + (a00 * (2 * Y2) - a02 * (2 * Y0)) * ys[1] + (-a00 * (2 * Y1)) * ys[2] + a00 * ys[3] + a02 * ys[5];
-    o.mrow[1] = (a12 * (2 * Y1) - a11 * (2 * Y2)) * ys[0] + (-a12 * (2 * Y0)) * ys[1] + a11 * (2 * Y0) * ys[2] + a11 * ys[4] + a12 * ys[5];
-    o.Jp[0] = (a00 * R[0] + a02 * R[6]) * psc[0];
-    o.Jp[1] = (a00 * R[1] + a02 * R[7]) * psc[1];
-    o.Jp[2] = (a00 * R[2] + a02 * R[8]) * psc[2];
-    o.Jp[3] = (a11 * R[3] + a12 * R[6]) * psc[0];
-    o.Jp[4] = (a11 * R[4] + a12 * R[7]) * psc[1];
-    o.Jp[5] = (a11 * R[5] + a12 * R[8]) * psc[2];
-  }
-  if (meta & kRecHasDepth) {
-    if (!(Zc > 0.0)) {
-      o.ok = false;
-    } else {
-      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
-      // the robust weight alone (loss_eval's rho1): the loss value is not needed here
-      double rho1 = 1.0;
-      if (L.depth_type == MPSFM_LOSS_SOFT_L1) rho1 = fmax(DBL_MIN, 1.0 / sqrt(1.0 + rd * rd * (1.0 / (a * a))));
-      else if (L.depth_type == MPSFM_LOSS_CAUCHY) rho1 = fmax(DBL_MIN, 1.0 / (1.0 + rd * rd * (1.0 / (a * a))));
-      const double sw = sqrt(m * rho1);
-      const double w = sw * iz;
-      o.r[2] = sw * rd;
-      o.mrow[2] = w * (2 * Y1) * ys[0] + (-w * (2 * Y0)) * ys[1] + w * ys[5];
-      o.Jp[6] = w * R[6] * psc[0];
-      o.Jp[7] = w * R[7] * psc[1];
-      o.Jp[8] = w * R[8] * psc[2];
-    }
-  }
-}
-
-// cost only (candidate point)
-__device__ __forceinline__ double record_cost(const double* __restrict__ cam, const double* X, uint32_t meta,
-                                              double u, double v, double d, double m, double a,
-                                              const LossParams& L, bool& ok) {
-  const double Xc = cam[0] * X[0] + cam[1] * X[1] + cam[2] * X[2] + cam[9];
-  const double Yc = cam[3] * X[0] + cam[4] * X[1] + cam[5] * X[2] + cam[10];
-  const double Zc = cam[6] * X[0] + cam[7] * X[1] + cam[8] * X[2] + cam[11];
-  double cost = 0.0;
-  if (meta & kRecHasReproj) {
-    const double iz = 1.0 / Zc;
-    const double r0 = cam[12] * Xc * iz + cam[14] - u;
-    const double r1 = cam[13] * Yc * iz + cam[15] - v;
-    double rho0, rho1;
-    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
-    cost += 0.5 * L.reproj_mag * rho0;
-    ok = ok && isfinite(r0) && isfinite(r1);
-  }
-  if (meta & kRecHasDepth) {
-    if (!(Zc > 0.0)) {
-      ok = false;
-    } else {
-      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
-      double rho0, rho1;
-      loss_eval(L.depth_type, a, rd * rd, rho0, rho1);
-      cost += 0.5 * m * rho0;
-    }
-  }
-  return cost;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
-  return v;
-}
-
-enum { MODE_FULL = 0, MODE_DIAG = 1 };
 
 
 // Track sweep.  One workgroup per chunk of landmarks:
@@ -237,7 +50,8 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   __shared__ uint32_t s_ents[kEntStage];
 
   const int tid = threadIdx.x;
-  const ChunkHdr H = A.chunks[blockIdx.x];
+  const int cix = blockIdx.x + A.chunk0;  // FULL mode: the launch covers the chunks the dense sweep does not take
+  const ChunkHdr H = A.chunks[cix];
   const int nrec = H.nrec, npt = H.npt, ncam = H.ncam;
 
   // ---- P0: clear accumulators, stage chunk tables -----------------------------------------
@@ -255,15 +69,8 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     my_ps[0] = A.ps[3 * (H.pt0 + tid)]; my_ps[1] = A.ps[3 * (H.pt0 + tid) + 1]; my_ps[2] = A.ps[3 * (H.pt0 + tid) + 2];
     s_const[tid] = my_kv == 0xffff;  // constant landmark: no Schur products (P3a)
   }
-  const bool dense = MODE == MODE_FULL && H.dense != 0 && !(A.dbg & 32);  // ablation flag 32: the products of dense chunks are dropped (they have no pair tables to fall back on)
   const bool ents_in_lds = (H.nent <= kEntStage);
-  // dense chunks: record of every (landmark, local camera), 0xffff: none (256 records need 9 bits).  Lives in the entry
-  // stage, which they do not use.
-  uint16_t* s_rec = reinterpret_cast<uint16_t*>(s_ents);
-  static_assert(kPtsMax * kDenseCams * 2 <= kEntStage * 4, "record table does not fit the entry stage");
-  if (dense) {
-    for (int i = tid; i < kPtsMax * kDenseCams / 2; i += kThreads) s_ents[i] = 0xffffffffu;
-  } else if (MODE == MODE_FULL && ents_in_lds) {
+  if (MODE == MODE_FULL && ents_in_lds) {
     for (int i = tid; i < H.nent; i += kThreads) s_ents[i] = A.ents[H.ent0 + i];
   }
   __syncthreads();
@@ -404,110 +211,12 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
           if (lcam < kTileCams) atomicAdd(&s_wv[(lpt % kCamCopies) * kGCopy + lcam * 6 + i], x);
           else atomicAdd(&A.wv[(size_t)slot * 6 + i], x);
         }
-        if (dense && my_bad == 0) s_rec[lpt * kDenseCams + lcam] = (uint16_t)tid;  // this record's Z takes part in the products
       }
     }
 
     __syncthreads();  // the rows of s_W now hold Z
 
 
-    // ---- P3b, dense chunks: S[ci,cj] -= Z_ci Z_cj^T for all local camera pairs at once as M M^T on the matrix pipe -----
-    // M is the (6 ncam) x (3 npt) matrix of the chunk's Z blocks (zero where a camera does not see a landmark; cameras of a
-    // chunk see most of its landmarks, so the dense product is barely more arithmetic than the pair list).  48 rows = three
-    // 16-row tiles, six tile pairs; the K index of an instruction is a LANDMARK (the four lane quarters feed four
-    // consecutive landmarks, one coordinate per instruction); the four waves split the landmarks and add their partial
-    // tiles into the packed 6x6 blocks in LDS.  Against six lanes per block summing a pair list on the vector pipe
-    // (LDS-bandwidth-bound: 126 doubles read per pair) this reads 9 doubles per lane and four landmarks.
-    if (dense) {
-      typedef double v4d __attribute__((ext_vector_type(4)));
-      const int lane = tid & 63, wave = tid >> 6;
-      const int rc = lane & 15, kq = lane >> 4;
-      for (int i = tid; i < (ncam * (ncam + 1) / 2) * 36; i += kThreads) s_stage[i] = 0.0;
-      int cam_of[3], a3_of[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) { const int r = 16 * t + rc; cam_of[t] = r / 6; a3_of[t] = (r - 6 * cam_of[t]) * 3; }
-      v4d acc[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
-      __syncthreads();
-      if (!(A.dbg & 2))
-        for (int g = wave; 4 * g < npt; g += kThreads / 64) {
-          const int p = 4 * g + kq;
-          double x[3][3];
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            if (16 * t >= 6 * ncam) { x[t][0] = x[t][1] = x[t][2] = 0.0; continue; }
-            const int rec = p < npt ? (int)s_rec[p * kDenseCams + cam_of[t]] : 0xffff;
-            const double* z = &s_W[(rec == 0xffff ? 0 : rec) * kWStride + a3_of[t]];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const double v = z[c]; x[t][c] = rec == 0xffff ? 0.0 : v; }
-          }
-          // 6 ncam rows: up to two cameras fill one 16-row tile, up to five two (three of the six tile pairs)
-          if (ncam <= 2) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[0][c], acc[0], 0, 0, 0);
-          } else if (ncam <= 5) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[0][c], acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[1][c], acc[1], 0, 0, 0);
-              acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[1][c], acc[3], 0, 0, 0);
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[0][c], acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[1][c], acc[1], 0, 0, 0);
-              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0][c], x[2][c], acc[2], 0, 0, 0);
-              acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[1][c], acc[3], 0, 0, 0);
-              acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1][c], x[2][c], acc[4], 0, 0, 0);
-              acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2][c], x[2][c], acc[5], 0, 0, 0);
-            }
-          }
-        }
-      // accumulator element r of lane l: row (l >> 4) + 4 r, column l & 15 of its tile pair
-      {
-        const int tis[6] = {0, 0, 0, 1, 1, 2}, tjs[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          if (16 * tjs[q] >= 6 * ncam) continue;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * tis[q] + kq + 4 * r, col = 16 * tjs[q] + rc;
-            const int ci = row / 6, cj = col / 6;
-            if (cj < ncam && ci <= cj) {
-              const double v = acc[q][r];
-              if (v != 0.0) atomicAdd(&s_stage[(cj * (cj + 1) / 2 + ci) * 36 + (row - 6 * ci) * 6 + (col - 6 * cj)], v);
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (!(A.dbg & 4)) {
-        const int nb = ncam * (ncam + 1) / 2;
-        for (int idx = tid; idx < nb * 36; idx += kThreads) {
-          const int b = idx / 36, el = idx - b * 36;
-          int cj = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
-          while (cj * (cj + 1) / 2 > b) --cj;
-          while ((cj + 1) * (cj + 2) / 2 <= b) ++cj;
-          const int ci = b - cj * (cj + 1) / 2;
-          const int ra = el / 6, cb = el - ra * 6;
-          double v = -s_stage[idx];
-          if (ci == cj) {
-            // diagonal blocks keep their upper triangle only; the camera's own U block goes out with the same atomic (its
-            // diagonal also into diag U) instead of a second pass over the same addresses in P4
-            if (cb < ra) continue;
-            const int u = ra * 6 - (ra * (ra - 1)) / 2 + (cb - ra);
-            double uu = 0.0;
-#pragma unroll
-            for (int q = 0; q < kCamCopies; ++q) uu += s_U[q * kUCopy + ci * 21 + u];
-            v += uu;
-            if (ra == cb && uu != 0.0) atomicAdd(&A.diagU[(size_t)s_slot[ci] * 6 + ra], uu);
-          }
-          if (v != 0.0) atomicAdd(&A.Sblk[sky_block(A.sky, s_slot[ci], s_slot[cj]) * 36 + el], v);
-        }
-      }
-    } else
     // ---- P3b: Schur pairs, block-major:  S[ci,cj] -= sum_pairs Z_i Z_j^T  (= W_i (V+D)^-1 W_j^T) ---------
     // Rounds of kGroups blocks: six lanes sum one block in registers, park it in LDS, then the whole
     // workgroup flushes the round with lanes running along the 36 contiguous doubles of a block
@@ -520,8 +229,8 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
         const int b = b0 + grp;
         if (grp < kGroups && b < nblk) {
           // entry offsets are chunk-relative
-          int e = A.blk_ent_start[H.blk0 + blockIdx.x + b];
-          const int e1 = A.blk_ent_start[H.blk0 + blockIdx.x + b + 1];
+          int e = A.blk_ent_start[H.blk0 + cix + b];
+          const int e1 = A.blk_ent_start[H.blk0 + cix + b + 1];
           const uint32_t* ep = ents_in_lds ? s_ents : (A.ents + H.ent0);
           double acc[6] = {0, 0, 0, 0, 0, 0};
           uint32_t ent = (e < e1) ? ep[e] : 0u;
@@ -569,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
   __syncthreads();
 
   // ---- P4: flush the per-camera LDS accumulators, chunk partials ------------------------------
-  if (MODE == MODE_FULL && !dense) {  // dense chunks have sent U with their diagonal Schur blocks
+  if (MODE == MODE_FULL) {
     for (int idx = tid; idx < kTileCams * 21; idx += kThreads) {
       const int lc = idx / 21;
       double v = s_U[idx];
@@ -605,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
     if ((tid & 63) == 0) { s_red[w] = c; s_red[4 + w] = b; s_red[8 + w] = g; }
     __syncthreads();
     if (tid == 0) {
-      double* p = A.part + (size_t)blockIdx.x * 4;
+      double* p = A.part + (size_t)cix * 4;
       p[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
       p[1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
       p[2] = fmax(fmax(s_red[8], s_red[9]), fmax(s_red[10], s_red[11]));

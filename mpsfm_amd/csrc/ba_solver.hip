@@ -33,6 +33,9 @@ namespace mpsfm {
 void init_tile_tables(hipStream_t);
 void launch_track_sweep(const SweepArgs&, int nchunks, bool diag_only, hipStream_t);
 void launch_update_sweep(const SweepArgs&, int nchunks, hipStream_t);
+void launch_track_sweep_dense(const SweepArgs&, int nchunks, hipStream_t);
+void launch_reduce_slabs(const RedDest* dests, int ndest, const int32_t* srcs, const double* slab, double* Sblk, double* gc, double* wv, double* diagU,
+                         const LmCtl* ctl, hipStream_t);
 void launch_cost_records(const CostArgs&, int nblocks, hipStream_t);
 void launch_reduce_cols(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out, hipStream_t,
                         double* out2 = nullptr);
@@ -441,6 +444,11 @@ struct mpsfm_ba_handle {
   int64_t nrec = 0, nfixed = 0, nblocks_total = 0, nblocks_reduced = 0;
   double nblocks_global = 0, nblocks_reduced_global = 0, nvarpts_global = 0;
   int ncv = 0, n = 0, nt = 0, nchunks = 0, nlong = 0;
+  int n_dense = 0;                  // chunks [0, n_dense) are swept by k_track_sweep_dense, the rest by the general kernel
+  double* d_slab = nullptr;         // slabs of the dense chunks
+  RedDest* d_red_dests = nullptr;   // slab reduction: destination parts and their sources
+  int32_t* d_red_srcs = nullptr;
+  int n_red_dests = 0;
   LongHdr* d_lhdr = nullptr;
   double* d_wl = nullptr;
   int64_t red_count = 0, sblk_count = 0, sblk_blocks = 0;
@@ -491,7 +499,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_cs, h->d_camtab, h->d_camtab2, h->d_intr_idx, h->d_cam_slot, h->d_ps, h->d_diagV, h->d_chunks,
                   h->d_chunk_cams, h->d_rec_cam, h->d_rec_pt, h->d_pt_rec_start, h->d_blk_ent_start, h->d_blk_desc, h->d_ents, h->d_rec_meta, h->d_pt_kv,
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
-                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl,
+                  h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl, h->d_slab, h->d_red_dests, h->d_red_srcs,
                   h->d_sky_first, h->d_sky_start, h->d_sky_index,
                   h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm, h->d_lp_live, h->d_lp_col_slot};
   for (void* p : ptrs) cached_free(p);
@@ -1034,6 +1042,27 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   });
   auto first_long = std::stable_partition(order.begin(), order.end(), [&](int p) { return !long_flag[(size_t)p]; });
   h->np_chunked = (int64_t)(first_long - order.begin());
+  // Landmarks the dense sweep cannot take — more than kDenseCams variable cameras, or two records of one camera for a variable
+  // landmark — go behind the others (same relative order), so that they form chunks of their own for the general kernel and
+  // every other chunk is dense by construction (the cut below keeps those within kDenseCams cameras / kDensePts landmarks).
+  const bool dense_on = !(std::getenv("MPSFM_SWEEP_DENSE") && std::atoi(std::getenv("MPSFM_SWEEP_DENSE")) == 0);
+  std::vector<uint8_t> heavy_flag((size_t)npu + 1, dense_on ? 0 : 1);
+  if (dense_on) {
+    parallel_ranges(h->np_chunked, 8192, [&](int64_t q0, int64_t q1) {
+      for (int64_t q = q0; q < q1; ++q) {
+        const int p = order[(size_t)q];
+        int distinct = 0, last = -2;
+        bool dup = false;
+        for (int64_t r = prec[p]; r < prec[p + 1]; ++r) {
+          if (recs[r].slot < 0) continue;
+          if (recs[r].slot != last) { ++distinct; last = recs[r].slot; }
+          else dup = true;  // records are slot-sorted: two of one camera are neighbours
+        }
+        heavy_flag[(size_t)p] = (distinct > kDenseCams || (dup && !P->pt_const[p])) ? 1 : 0;
+      }
+    });
+    std::stable_partition(order.begin(), first_long, [&](int p) { return !heavy_flag[(size_t)p]; });
+  }
   const int64_t n_long = (int64_t)(order.end() - first_long);
   {
     std::vector<uint8_t> seen((size_t)npu + 1, 0);
@@ -1099,7 +1128,9 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
             std::set_union(cur_cams.begin(), cur_cams.end(), pc.begin(), pc.end(), std::back_inserter(uni));
             nuni = uni.size();
           }
-          const bool too_big = (c_nrec + r_p > kObsMax) || (k - c_first + 1 > kPtsMax) || ((int)nuni > kLocalCamsMax);
+          const bool hv = heavy_flag[(size_t)p] != 0;
+          const bool too_big = (c_nrec + r_p > kObsMax) || (k - c_first + 1 > (hv ? kPtsMax : kDensePts)) || ((int)nuni > (hv ? kLocalCamsMax : kDenseCams)) ||
+                               (hv != (heavy_flag[(size_t)order[(size_t)c_first]] != 0));  // dense and general landmarks never share a chunk
           if (k > c_first && too_big) {
             close_chunk(k);
             cur_cams = pc;
@@ -1133,7 +1164,6 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       double nvarpts = 0;
     };
     const int nch = (int)chunks.size();
-    const bool dense_on = !(std::getenv("MPSFM_SWEEP_DENSE") && std::atoi(std::getenv("MPSFM_SWEEP_DENSE")) == 0);
     const int cparts = std::max(1, std::min(host_threads(), nch / 48));
     std::vector<ChunkPart> cp((size_t)cparts);
     run_parts(cparts, [&](int t, int nparts) {
@@ -1174,8 +1204,9 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
           }
         }
         // Chunks that form their Schur blocks as one dense product (k_track_sweep) need no pair tables at all.
-        H.dense = (H.ncam <= kDenseCams && !dup && dense_on) ? 1 : 0;
-        H.pad_ = 0;
+        H.dense = heavy_flag[(size_t)order[(size_t)c_first]] ? 0 : 1;  // by construction: <= kDenseCams cameras, <= kDensePts landmarks, no duplicates
+        H.slab0 = 0;
+        (void)dup;
         if (!H.dense) {
           for (int64_t k = c_first; k < end_pt; ++k) {
             const int p = order[k];
@@ -1394,6 +1425,73 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     }
   }
 
+  // -- slabs of the dense chunks and the tables of their reduction (k_reduce_slabs): per destination — a block of S or a camera's
+  //    vectors — the slab positions that contribute, in chunk order; destinations with many sources are split into parts
+  std::vector<RedDest> red_dests;
+  std::vector<int32_t> red_srcs;
+  int64_t slab_units = 0;
+  {
+    h->n_dense = 0;
+    for (size_t c = 0; c < chunks.size(); ++c) {
+      ChunkHdr& H = chunks[c];
+      if (!H.dense) continue;
+      if ((int)c != h->n_dense) return fail(MPSFM_EUNSUPPORTED, "internal: dense chunks must precede the general ones");
+      H.slab0 = (int32_t)slab_units;
+      slab_units += slab_doubles(H.ncam) / 18;
+      if (slab_units > (int64_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "slabs of the dense chunks exceed 2^31 units");
+      h->n_dense = (int)c + 1;
+    }
+    const int64_t nsb = h->sblk_blocks;
+    auto host_sky = [&](int si, int sj) -> int64_t {
+      return use_graph ? (int64_t)h->sky_index[(size_t)sj * (size_t)h->ncv + (size_t)si] : h->sky_start[(size_t)sj] + (si - h->sky_first[(size_t)sj]);
+    };
+    const size_t ndst = (size_t)nsb + (size_t)std::max(h->ncv, 0);
+    std::vector<int32_t> cnt(ndst + 1, 0);
+    for (int pass = 0; pass < 2; ++pass) {  // count, then place (chunk order within a destination)
+      if (pass == 1) {
+        for (size_t d = 1; d <= ndst; ++d) cnt[d] += cnt[d - 1];
+        red_srcs.resize((size_t)cnt[ndst]);
+      }
+      for (int c = 0; c < h->n_dense; ++c) {
+        const ChunkHdr& H = chunks[(size_t)c];
+        const int32_t* cams = chunk_cams.data() + H.cam0;
+        const int nb = H.ncam * (H.ncam + 1) / 2;
+        for (int cj = 0; cj < H.ncam; ++cj) {
+          for (int ci = 0; ci <= cj; ++ci) {
+            const int64_t b = host_sky(cams[ci], cams[cj]);
+            if (b < 0) continue;  // two cameras of the chunk that share no landmark anywhere: their product is exactly zero, S has no such block
+            if (b >= nsb) return fail(MPSFM_EUNSUPPORTED, "internal: block index beyond S");
+            if (pass == 0) cnt[(size_t)b + 1]++;
+            else red_srcs[(size_t)cnt[(size_t)b]++] = H.slab0 + 2 * (cj * (cj + 1) / 2 + ci);
+          }
+          const size_t d = (size_t)nsb + (size_t)cams[cj];
+          if (pass == 0) cnt[d + 1]++;
+          else red_srcs[(size_t)cnt[d]++] = H.slab0 + 2 * nb + cj;
+        }
+      }
+    }
+    // after the placing pass cnt[d] is the END of destination d
+    std::vector<uint8_t> is_diag((size_t)nsb, 0);
+    for (int sl = 0; sl < h->ncv; ++sl) {
+      if (use_graph && h->plan.nat_of_slot[(size_t)sl] < 0) continue;
+      const int64_t b = host_sky(sl, sl);
+      if (b >= 0 && b < nsb) is_diag[(size_t)b] = 1;
+    }
+    constexpr int kPart = 16;
+    for (size_t d = 0; d < ndst; ++d) {
+      const int32_t s0 = d == 0 ? 0 : cnt[d - 1], s1 = cnt[d];
+      for (int32_t q = s0; q < s1; q += kPart) {
+        RedDest R;
+        R.kind = d >= (size_t)nsb ? 2 : (is_diag[d] ? 1 : 0);
+        R.dst = d >= (size_t)nsb ? (int32_t)(d - (size_t)nsb) : (int32_t)d;
+        R.s0 = q; R.s1 = std::min(q + kPart, s1);
+        red_dests.push_back(R);
+      }
+    }
+    h->n_red_dests = (int)red_dests.size();
+  }
+  lap("slab reduction tables");
+
   // -- fixed records (landmark index re-ordered)
   std::vector<int32_t> fx_cam, fx_pt; std::vector<uint32_t> fx_meta; std::vector<double> fx_xy, fx_d, fx_m, fx_a;
   for (size_t i = 0; i < fixed.size(); ++i) {
@@ -1425,6 +1523,9 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_blk_ent_start, blk_ent_start))) return rc;
   if ((rc = dev_upload(&h->d_ents, ents))) return rc;
   if ((rc = dev_upload(&h->d_pt_kv, pt_kv))) return rc;
+  if ((rc = dev_upload(&h->d_red_dests, red_dests))) return rc;
+  if ((rc = dev_upload(&h->d_red_srcs, red_srcs))) return rc;
+  if ((rc = dev_alloc(&h->d_slab, (size_t)std::max<int64_t>(slab_units, 1) * 18))) return rc;
   if ((rc = dev_upload(&h->d_fx_cam, fx_cam))) return rc;
   if ((rc = dev_upload(&h->d_fx_pt, fx_pt))) return rc;
   if ((rc = dev_upload(&h->d_fx_meta, fx_meta))) return rc;
@@ -1537,6 +1638,7 @@ static SweepArgs sweep_args(mpsfm_ba_handle* h, double radius, const LmCtl* ctl 
   a.sky = BlockSky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv};
   a.Sblk = h->d_Sblk; a.gc = h->d_gc; a.wv = h->d_wv; a.diagU = h->d_diagU; a.part = h->d_part; a.diagV = h->d_diagV;
   a.yc = h->d_yc; a.camtab2 = h->d_camtab2; a.pts2 = h->d_pts2; a.part2 = h->d_part2;
+  a.slab = h->d_slab; a.chunk0 = 0;
   return a;
 }
 
@@ -1576,13 +1678,22 @@ static int prepare_scales(mpsfm_ba_handle* h) {
   return 0;
 }
 
+// the full track sweep: dense chunks through their slabs (k_track_sweep_dense + k_reduce_slabs), the others and the long
+// tracks through the general kernels (global atomics); all of them add into the zeroed reduced buffer
+static void launch_sweeps(mpsfm_ba_handle* h, SweepArgs a, hipStream_t s) {
+  launch_track_sweep_dense(a, h->n_dense, s);
+  launch_reduce_slabs(h->d_red_dests, h->n_red_dests, h->d_red_srcs, h->d_slab, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, a.ctl, s);
+  a.chunk0 = h->n_dense;
+  launch_track_sweep(a, h->nchunks - h->n_dense, false, s);
+}
+
 // one track sweep at the current state: fills the reduced buffer and its scalar tail
 // (inside the solve loop the prologue kernel has zeroed the buffer; single-rank runs reduce the partials with the decision)
 static int run_track_sweep(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullptr, bool in_loop = false) {
   hipStream_t s = h->stream;
   if (!in_loop) launch_zero(h->d_red, h->red_count, ctl, s);
   SweepArgs a = sweep_args(h, radius, ctl);
-  launch_track_sweep(a, h->nchunks, false, s);
+  launch_sweeps(h, a, s);
   if (h->nchunks + h->nlong > 0 && !(in_loop && !sharded(h)))
     launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, sharded(h) ? nullptr : h->d_scal + U_X_COST);
   if (sharded(h)) launch_gmax_to_slot(h->d_redsc, h->opt.rank > 0 ? h->opt.rank : 0, s);
@@ -1755,6 +1866,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   return finish(0);
 }
 
+static thread_local int g_cu_count = 256;
 static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, const mpsfm_ba_options* o, mpsfm_ba_handle** out) {
   if (!out) return fail(MPSFM_EINVAL, "out is NULL");
   *out = nullptr;
@@ -1775,13 +1887,16 @@ static int create_impl(const mpsfm_ba_problem* P, const mpsfm_ba_state* st, cons
     // the architecture of a device does not change: query it once per process and device
     static std::mutex mu;
     static std::vector<std::string> arch;
+    static std::vector<int> cus;
     std::lock_guard<std::mutex> lk(mu);
-    if ((int)arch.size() < ndev) arch.resize((size_t)ndev);
+    if ((int)arch.size() < ndev) { arch.resize((size_t)ndev); cus.resize((size_t)ndev, 256); }
     if (arch[(size_t)o->device].empty()) {
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, o->device));
       arch[(size_t)o->device] = prop.gcnArchName;
+      cus[(size_t)o->device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    g_cu_count = cus[(size_t)o->device];
     if (std::strncmp(arch[(size_t)o->device].c_str(), "gfx950", 6) != 0)
       return fail(MPSFM_ENODEVICE, std::string("device is ") + arch[(size_t)o->device] + ", this library is built for gfx950 only");
   }
@@ -2019,16 +2134,41 @@ int mpsfm_ba_sweep_once(mpsfm_ba_handle* h, double radius, float* elapsed_ms) {
   if (!h->scales_ready) if (int rc = prepare_scales(h)) return rc;
   HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double) * (size_t)h->red_count, h->stream));
   SweepArgs a = sweep_args(h, radius);
+  // the three parts of the sweep between events: dense chunks | reduction of their slabs | general chunks and long tracks
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-  launch_track_sweep(a, h->nchunks, false, h->stream);
+  launch_track_sweep_dense(a, h->n_dense, h->stream);
   HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  launch_reduce_slabs(h->d_red_dests, h->n_red_dests, h->d_red_srcs, h->d_slab, h->d_Sblk, h->d_gc, h->d_wv, h->d_diagU, nullptr, h->stream);
+  HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  a.chunk0 = h->n_dense;
+  launch_track_sweep(a, h->nchunks - h->n_dense, false, h->stream);
+  HIP_TRY(hipEventRecord(h->ev[3], h->stream));
   if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
   h->last_radius = radius;
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
   if (elapsed_ms) *elapsed_ms = ms;
+  return 0;
+}
+
+// Diagnostics (scripts/dbg_sweep_trace.py): the first `count` 8-byte words of the landmark-diagonal buffer, where the dense sweep leaves
+// its phase stamps under debug flag 128.
+int mpsfm_debug_read_trace(mpsfm_ba_handle* h, long long* out, int64_t count) {
+  if (!h || !out || count < 0 || count > 3 * std::max<int64_t>(h->np, 1)) return fail(MPSFM_EINVAL, "bad trace request");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(out, h->d_diagV, sizeof(long long) * (size_t)count, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mpsfm_ba_sweep_parts(mpsfm_ba_handle* h, float ms[3], int64_t info[4]) {
+  if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  if (ms)
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], h->ev[k], h->ev[k + 1]));
+  if (info) { info[0] = h->n_dense; info[1] = h->nchunks - h->n_dense; info[2] = h->nlong; info[3] = h->n_red_dests; }
   return 0;
 }
 

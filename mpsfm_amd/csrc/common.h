@@ -24,7 +24,7 @@ namespace mpsfm {
 #define MPSFM_ENT_STAGE 1024
 #endif
 #ifndef MPSFM_OBS_MAX
-#define MPSFM_OBS_MAX 256
+#define MPSFM_OBS_MAX 252  // 252 records x 144 B of Z + the accumulators = 53.4 KB of LDS: three workgroups of the dense sweep per CU
 #endif
 
 // ---- track-sweep chunk geometry ----------------------------------------------------------
@@ -55,11 +55,20 @@ struct ChunkHdr {
   int32_t cam0, ncam;    // local camera list in chunk_cams[cam0 ..)
   int32_t blk0, nblk;    // Schur work items (a destination block of S + a run of its pairs) of this chunk
   int32_t ent0, nent;    // the chunk's pair entries
-  int32_t dense;         // 1: at most kDenseCams local cameras and one record per (camera, variable landmark): Schur products as one
-                         //    small dense product on the matrix pipe (k_track_sweep), the pair tables are not used
-  int32_t pad_;
+  int32_t dense;         // 1: at most kDenseCams local cameras, kDensePts landmarks and one record per (camera, variable landmark): swept by
+                         //    k_track_sweep_dense (Schur products as one small dense product on the matrix pipe, results through the chunk's
+                         //    slab); such chunks have no pair tables
+  int32_t slab0;         // dense chunks: start of the chunk's slab in SweepArgs::slab, in units of 18 doubles
 };
-constexpr int kDenseCams = 8;  // 8 cameras x 6 rows = 48 rows = three 16-row MFMA tiles
+constexpr int kDenseCams = 16;  // 16 cameras x 6 rows = 96 rows = six 16-row MFMA tiles
+constexpr int kDensePts = 96;   // landmarks of a dense chunk
+// slab of a dense chunk: [ncam (ncam + 1) / 2 blocks (ci <= cj at cj (cj + 1) / 2 + ci) x 36][ncam x (g_c 6 | W V^-1 g_p 6 | diag U 6)] doubles,
+// written with plain stores by k_track_sweep_dense and summed per destination by k_reduce_slabs
+__host__ __device__ inline int64_t slab_doubles(int ncam) { return (int64_t)(ncam * (ncam + 1) / 2) * 36 + (int64_t)ncam * 18; }
+
+// One destination of the slab reduction: a 6x6 block of S (kind 0: all 36 entries, 1: a diagonal block, upper triangle) or a camera's
+// vectors (kind 2).  Destinations with many sources are split into parts (every part adds atomically into the zeroed buffer).
+struct RedDest { int32_t kind; int32_t dst; int32_t s0, s1; };
 
 // A landmark whose track does not fit a chunk (more than kObsMax records or kLocalCamsMax cameras)
 // is swept by a workgroup of its own that strides over the records (k_long_track_sweep).
@@ -117,18 +126,48 @@ __device__ inline bool lm_over(const LmCtl* c) { return c != nullptr && __hip_at
 __device__ inline double lm_radius_of(const LmCtl* c) { return __hip_atomic_load(&c->radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- small device math -------------------------------------------------------------------
+// Reciprocal, square root and reciprocal square root in a handful of instructions: the hardware estimate (v_rcp_f64 / v_rsq_f64,
+// ~2^-22 relative) refined by two Newton steps (error ~ e^4: below one ulp; the last bit may differ from the IEEE-rounded quotient
+// the compiler's ~30-instruction expansion of `/` and sqrt() delivers).  The sweeps take five quotients and three roots per record.
+__host__ __device__ inline double fast_rcp(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return fma(y, fma(-x, y, 1.0), y);
+#else
+  return 1.0 / x;
+#endif
+}
+// s = sqrt(x), r = 1 / sqrt(x) for x > 0 (x == 0: s = 0, r = inf)
+__host__ __device__ inline void fast_sqrt_rsqrt(double x, double& s, double& r) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double e = fma(-g, h, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  e = fma(-g, h, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  s = x == 0.0 ? 0.0 : g;
+  r = x == 0.0 ? y : 2.0 * h;
+#else
+  s = sqrt(x); r = 1.0 / s;
+#endif
+}
+__host__ __device__ inline double fast_sqrt(double x) { double s, r; fast_sqrt_rsqrt(x, s, r); return s; }
+
 __host__ __device__ inline void loss_eval(int type, double a, double s, double& rho0, double& rho1) {
   if (type == MPSFM_LOSS_SOFT_L1) {
-    const double b = a * a, c = 1.0 / b;
+    const double b = a * a, c = fast_rcp(b);
     const double sum = 1.0 + s * c;
-    const double tmp = sqrt(sum);
+    double tmp, itmp;
+    fast_sqrt_rsqrt(sum, tmp, itmp);
     rho0 = 2.0 * b * (tmp - 1.0);
-    rho1 = fmax(DBL_MIN, 1.0 / tmp);
+    rho1 = fmax(DBL_MIN, itmp);
   } else if (type == MPSFM_LOSS_CAUCHY) {
-    const double b = a * a, c = 1.0 / b;
+    const double b = a * a, c = fast_rcp(b);
     const double sum = 1.0 + s * c;
     rho0 = b * log(sum);
-    rho1 = fmax(DBL_MIN, 1.0 / sum);
+    rho1 = fmax(DBL_MIN, fast_rcp(sum));
   } else {
     rho0 = s;
     rho1 = 1.0;
@@ -190,16 +229,16 @@ __host__ __device__ inline bool spd3_inverse(const double* V, double* Vi) {
 __host__ __device__ inline bool spd3_inv_factor(const double* V, double* F) {
   const double a = V[0], b = V[1], c = V[2], d = V[3], e = V[4], f = V[5];
   if (!(a > 0.0)) return false;
-  const double l00 = sqrt(a);
-  const double l10 = b / l00, l20 = c / l00;
+  double l00, i00, l11, i11, l22, i22;  // the factor's diagonal and its inverse from one reciprocal square root each
+  fast_sqrt_rsqrt(a, l00, i00);
+  const double l10 = b * i00, l20 = c * i00;
   const double t11 = d - l10 * l10;
   if (!(t11 > 0.0)) return false;
-  const double l11 = sqrt(t11);
-  const double l21 = (e - l20 * l10) / l11;
+  fast_sqrt_rsqrt(t11, l11, i11);
+  const double l21 = (e - l20 * l10) * i11;
   const double t22 = f - l20 * l20 - l21 * l21;
   if (!(t22 > 0.0)) return false;
-  const double l22 = sqrt(t22);
-  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  fast_sqrt_rsqrt(t22, l22, i22);
   const double i10 = -l10 * i00 * i11;
   const double i21 = -l21 * i11 * i22;
   const double i20 = -(l20 * i00 + l21 * i10) * i22;
@@ -276,6 +315,9 @@ struct SweepArgs {
   int32_t nlong, nchunks;
   const int32_t* cam_slot;  // [nc] reduced-system slot or -1
   double* wl;               // W scratch of the long tracks
+  double* slab;             // slabs of the dense chunks (k_track_sweep_dense -> k_reduce_slabs)
+  int32_t chunk0;           // first chunk of this launch (blockIdx.x + chunk0 indexes `chunks` and `part`)
+  int32_t pad0_;
   // outputs of the track sweep (accumulated, caller zeroes)
   BlockSky sky;    // where a block of S lives
   double* Sblk;    // block skyline of the upper block triangle, 36 doubles per block

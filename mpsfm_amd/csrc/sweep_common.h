@@ -1,0 +1,200 @@
+// Device functions shared by the sweep kernels (ba_kernels.hip, sweep_dense.hip): residual blocks of one merged record
+// (reprojection functor of pycolmap's bundle adjuster + the fork's log-depth functor, reference call sites
+// mpsfm/sfm/mapper/bundle_adjustment.py:85-104, 163-176) with analytic Jacobians, Ceres' loss corrector folded in.
+#pragma once
+#include "common.h"
+
+namespace mpsfm {
+
+struct RecLin {
+  double Jc[18];  // 3 x 6 (rows 0,1 reprojection, row 2 log-depth), robustified + scaled
+  double Jp[9];   // 3 x 3
+  double r[3];
+  double cost;
+  bool ok;
+};
+
+// residual blocks of one merged record at camera `cam` (table row) and landmark X
+__device__ __forceinline__ void linearize_record(const double* __restrict__ cam, const double* X,
+                                                 const double* psc, uint32_t meta, double u, double v,
+                                                 double d, double m, double a, const LossParams& L,
+                                                 RecLin& o) {
+  double c[24];
+  const double2* c2 = reinterpret_cast<const double2*>(cam);
+#pragma unroll
+  for (int i = 0; i < 11; ++i) { const double2 t = c2[i]; c[2 * i] = t.x; c[2 * i + 1] = t.y; }
+  const double* R = c; const double* t = c + 9; const double* K = c + 12; const double* cs = c + 16;
+  const double Y0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+  const double Y1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+  const double Y2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+  const double Xc = Y0 + t[0], Yc = Y1 + t[1], Zc = Y2 + t[2];
+  const double iz = fast_rcp(Zc);
+  o.cost = 0.0;
+  o.ok = true;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) o.Jc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.Jp[i] = 0.0;
+  o.r[0] = o.r[1] = o.r[2] = 0.0;
+  if (meta & kRecHasReproj) {
+    const double r0 = K[0] * Xc * iz + K[2] - u;
+    const double r1 = K[1] * Yc * iz + K[3] - v;
+    double rho0, rho1;
+    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
+    o.cost += 0.5 * L.reproj_mag * rho0;
+    o.ok = o.ok && isfinite(r0) && isfinite(r1);
+    const double w = fast_sqrt(L.reproj_mag * rho1);
+    const double a00 = w * K[0] * iz, a02 = -w * K[0] * Xc * iz * iz;
+    const double a11 = w * K[1] * iz, a12 = -w * K[1] * Yc * iz * iz;
+    o.r[0] = w * r0; o.r[1] = w * r1;
+    o.Jc[0] = a02 * (2 * Y1) * cs[0];
+    o.Jc[1] = (a00 * (2 * Y2) - a02 * (2 * Y0)) * cs[1];
+    o.Jc[2] = -a00 * (2 * Y1) * cs[2];
+    o.Jc[3] = a00 * cs[3];
+    o.Jc[5] = a02 * cs[5];
+    o.Jc[6] = (a12 * (2 * Y1) - a11 * (2 * Y2)) * cs[0];
+    o.Jc[7] = -a12 * (2 * Y0) * cs[1];
+    o.Jc[8] = a11 * (2 * Y0) * cs[2];
+    o.Jc[10] = a11 * cs[4];
+    o.Jc[11] = a12 * cs[5];
+    o.Jp[0] = (a00 * R[0] + a02 * R[6]) * psc[0];
+    o.Jp[1] = (a00 * R[1] + a02 * R[7]) * psc[1];
+    o.Jp[2] = (a00 * R[2] + a02 * R[8]) * psc[2];
+    o.Jp[3] = (a11 * R[3] + a12 * R[6]) * psc[0];
+    o.Jp[4] = (a11 * R[4] + a12 * R[7]) * psc[1];
+    o.Jp[5] = (a11 * R[5] + a12 * R[8]) * psc[2];
+  }
+  if (meta & kRecHasDepth) {
+    if (!(Zc > 0.0)) {
+      o.ok = false;
+    } else {
+      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
+      double rho0, rho1;
+      loss_eval(L.depth_type, a, rd * rd, rho0, rho1);
+      o.cost += 0.5 * m * rho0;
+      const double sw = fast_sqrt(m * rho1);
+      const double w = sw * iz;
+      o.r[2] = sw * rd;
+      o.Jc[12] = w * (2 * Y1) * cs[0];
+      o.Jc[13] = -w * (2 * Y0) * cs[1];
+      o.Jc[17] = w * cs[5];
+      o.Jp[6] = w * R[6] * psc[0];
+      o.Jp[7] = w * R[7] * psc[1];
+      o.Jp[8] = w * R[8] * psc[2];
+    }
+  }
+}
+
+// The update sweep's view of a record: rows of Jp, the robustified residuals and mrow = Jc yc, with the camera Jacobian
+// folded into the products (ys = cs .* yc) instead of materialised — 36 registers less at the kernel's pressure peak, which
+// is what held it at four waves per SIMD — and without the loss value (one logarithm less per Cauchy block).
+struct RecUpd {
+  double Jp[9], r[3], mrow[3];
+  bool ok;
+};
+__device__ __forceinline__ void linearize_update(const double* __restrict__ cam, const double* X, const double* psc, uint32_t meta, double u, double v,
+                                                 double d, double m, double a, const LossParams& L, const double* yc, RecUpd& o) {
+  double c[24];
+  const double2* c2 = reinterpret_cast<const double2*>(cam);
+#pragma unroll
+  for (int i = 0; i < 11; ++i) { const double2 t = c2[i]; c[2 * i] = t.x; c[2 * i + 1] = t.y; }
+  const double* R = c; const double* t = c + 9; const double* K = c + 12; const double* cs = c + 16;
+  const double Y0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+  const double Y1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+  const double Y2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+  const double Xc = Y0 + t[0], Yc = Y1 + t[1], Zc = Y2 + t[2];
+  const double iz = fast_rcp(Zc);
+  double ys[6] = {0, 0, 0, 0, 0, 0};
+  if (yc) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ys[k] = cs[k] * yc[k];
+  }
+  o.ok = true;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.Jp[i] = 0.0;
+  o.r[0] = o.r[1] = o.r[2] = 0.0;
+  o.mrow[0] = o.mrow[1] = o.mrow[2] = 0.0;
+  if (meta & kRecHasReproj) {
+    const double r0 = K[0] * Xc * iz + K[2] - u;
+    const double r1 = K[1] * Yc * iz + K[3] - v;
+    double rho0, rho1;
+    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
+    o.ok = o.ok && isfinite(r0) && isfinite(r1);
+    const double w = fast_sqrt(L.reproj_mag * rho1);
+    const double a00 = w * K[0] * iz, a02 = -w * K[0] * Xc * iz * iz;
+    const double a11 = w * K[1] * iz, a12 = -w * K[1] * Yc * iz * iz;
+    o.r[0] = w * r0; o.r[1] = w * r1;
+    // the rows of Jc as in linearize_record, times ys
+    o.mrow[0] = a02 * (2 * Y1) * ys[0] + (a00 * (2 * Y2) - a02 * (2 * Y0)) * ys[1] + (-a00 * (2 * Y1)) * ys[2] + a00 * ys[3] + a02 * ys[5];
+    o.mrow[1] = (a12 * (2 * Y1) - a11 * (2 * Y2)) * ys[0] + (-a12 * (2 * Y0)) * ys[1] + a11 * (2 * Y0) * ys[2] + a11 * ys[4] + a12 * ys[5];
+    o.Jp[0] = (a00 * R[0] + a02 * R[6]) * psc[0];
+    o.Jp[1] = (a00 * R[1] + a02 * R[7]) * psc[1];
+    o.Jp[2] = (a00 * R[2] + a02 * R[8]) * psc[2];
+    o.Jp[3] = (a11 * R[3] + a12 * R[6]) * psc[0];
+    o.Jp[4] = (a11 * R[4] + a12 * R[7]) * psc[1];
+    o.Jp[5] = (a11 * R[5] + a12 * R[8]) * psc[2];
+  }
+  if (meta & kRecHasDepth) {
+    if (!(Zc > 0.0)) {
+      o.ok = false;
+    } else {
+      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
+      // the robust weight alone (loss_eval's rho1): the loss value is not needed here
+      double rho1 = 1.0;
+      if (L.depth_type == MPSFM_LOSS_SOFT_L1) { double t, it; fast_sqrt_rsqrt(1.0 + rd * rd * fast_rcp(a * a), t, it); rho1 = fmax(DBL_MIN, it); }
+      else if (L.depth_type == MPSFM_LOSS_CAUCHY) rho1 = fmax(DBL_MIN, fast_rcp(1.0 + rd * rd * fast_rcp(a * a)));
+      const double sw = fast_sqrt(m * rho1);
+      const double w = sw * iz;
+      o.r[2] = sw * rd;
+      o.mrow[2] = w * (2 * Y1) * ys[0] + (-w * (2 * Y0)) * ys[1] + w * ys[5];
+      o.Jp[6] = w * R[6] * psc[0];
+      o.Jp[7] = w * R[7] * psc[1];
+      o.Jp[8] = w * R[8] * psc[2];
+    }
+  }
+}
+
+// cost only (candidate point)
+__device__ __forceinline__ double record_cost(const double* __restrict__ cam, const double* X, uint32_t meta,
+                                              double u, double v, double d, double m, double a,
+                                              const LossParams& L, bool& ok) {
+  const double Xc = cam[0] * X[0] + cam[1] * X[1] + cam[2] * X[2] + cam[9];
+  const double Yc = cam[3] * X[0] + cam[4] * X[1] + cam[5] * X[2] + cam[10];
+  const double Zc = cam[6] * X[0] + cam[7] * X[1] + cam[8] * X[2] + cam[11];
+  double cost = 0.0;
+  if (meta & kRecHasReproj) {
+    const double iz = fast_rcp(Zc);
+    const double r0 = cam[12] * Xc * iz + cam[14] - u;
+    const double r1 = cam[13] * Yc * iz + cam[15] - v;
+    double rho0, rho1;
+    loss_eval(L.reproj_type, L.reproj_a, r0 * r0 + r1 * r1, rho0, rho1);
+    cost += 0.5 * L.reproj_mag * rho0;
+    ok = ok && isfinite(r0) && isfinite(r1);
+  }
+  if (meta & kRecHasDepth) {
+    if (!(Zc > 0.0)) {
+      ok = false;
+    } else {
+      const double rd = log(Zc) - d;  // d: log of the prior depth (ba_solver.hip)
+      double rho0, rho1;
+      loss_eval(L.depth_type, a, rd * rd, rho0, rho1);
+      cost += 0.5 * m * rho0;
+    }
+  }
+  return cost;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+enum { MODE_FULL = 0, MODE_DIAG = 1 };
+
+}  // namespace mpsfm
