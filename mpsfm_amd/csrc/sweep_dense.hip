@@ -50,6 +50,107 @@ __device__ __forceinline__ void seg_step(int my_lpt, double (&v)[9]) {
   }
 }
 
+// Schur products of a chunk with at most 7 cameras (three row tiles; 4 x 28 blocks of partial sums fit the Z rows' LDS): the
+// UNITS (landmark group, coordinate) are dealt to the four waves, every wave sums all tile pairs over its units — each Z row is
+// fetched by exactly one wave, a quarter of the operand traffic of the pair-per-wave form, and the waves finish together — then
+// the four partial sums meet in LDS (plain stores into a copy per wave over the no longer needed Z rows) and all threads write
+// U - sum to the slab along its 288-byte blocks.
+template <int NT>
+__device__ __forceinline__ void schur_units(double* s_W, const uint8_t* s_rec, const double* s_U, double* slab, int tid, int npt, int ncam,
+                                            int ncopy, int cstride, int dbg) {
+  constexpr int NP = NT * (NT + 1) / 2;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int rc = lane & 15, kq = lane >> 4;
+  int camt[NT], a3t[NT];
+  bool camv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r = 16 * t + rc;
+    camt[t] = r / 6; a3t[t] = (r - 6 * (r / 6)) * 3;
+    camv[t] = camt[t] < ncam; camt[t] = camv[t] ? camt[t] : 0;
+  }
+  v4d acc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int nunits = 3 * ((npt + 3) >> 2);
+  if (!(dbg & 2)) {
+    // two-stage pipeline over the wave's units u = wave, wave + 4, ...: record indices one unit ahead, then the operand
+    int rcur[NT], rnxt[NT];
+    double x[NT];
+    auto rec_request = [&](int u, int (&r)[NT]) {
+      const int pp = min(4 * (u / 3) + kq, npt - 1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) r[t] = (int)s_rec[pp * kDenseCams + camt[t]];
+    };
+    auto rec_fix = [&](int u, int (&r)[NT]) {
+      const bool pv = 4 * (u / 3) + kq < npt;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) r[t] = (pv && camv[t]) ? r[t] : 255;
+    };
+    int u = wave;
+    if (u < nunits) {
+      rec_request(u, rcur);
+      rec_fix(u, rcur);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) x[t] = s_W[(rcur[t] == 255 ? 0 : rcur[t]) * kWStride + a3t[t] + u % 3];
+      rec_request(min(u + 4, nunits - 1), rnxt);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) x[t] = rcur[t] == 255 ? 0.0 : x[t];
+    }
+    for (; u < nunits; u += 4) {
+      const int u1 = min(u + 4, nunits - 1), u2 = min(u + 8, nunits - 1);
+      double xn[NT];
+      rec_fix(u1, rnxt);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) xn[t] = s_W[(rnxt[t] == 255 ? 0 : rnxt[t]) * kWStride + a3t[t] + u1 % 3];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) rcur[t] = rnxt[t];
+      rec_request(u2, rnxt);
+      {
+        int q = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+          for (int tj = ti; tj < NT; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], x[tj], acc[q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) x[t] = rcur[t] == 255 ? 0.0 : xn[t];
+    }
+  }
+  const int nb = ncam * (ncam + 1) / 2;
+  __syncthreads();  // every wave is done with the Z rows
+  {
+    double* part = s_W + wave * (nb * 36);
+    int q = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int tj = ti; tj < NT; ++tj, ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ti + kq + 4 * r, col = 16 * tj + rc;
+          const int ci = row / 6, cj = col / 6;
+          if (cj < ncam && ci <= cj) part[(cj * (cj + 1) / 2 + ci) * 36 + (row - 6 * ci) * 6 + (col - 6 * cj)] = acc[q][r];
+        }
+  }
+  __syncthreads();
+  if (!(dbg & 4))
+    for (int idx = tid; idx < nb * 36; idx += kThreads) {
+      const int b = idx / 36, el = idx - b * 36;
+      int cj = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+      while (cj * (cj + 1) / 2 > b) --cj;
+      while ((cj + 1) * (cj + 2) / 2 <= b) ++cj;
+      const int ci = b - cj * (cj + 1) / 2;
+      const int ra = el / 6, cb = el - ra * 6;
+      double v = -((s_W[idx] + s_W[nb * 36 + idx]) + (s_W[2 * nb * 36 + idx] + s_W[3 * nb * 36 + idx]));
+      if (ci == cj && cb >= ra) {  // the camera's own U block rides on its diagonal Schur block (upper triangle; the lower one is not read)
+        const int uix = ra * 6 - (ra * (ra - 1)) / 2 + (cb - ra);
+        for (int c = 0; c < ncopy; ++c) v += s_U[(c * cstride + ci) * 21 + uix];
+      }
+      slab[idx] = v;
+    }
+}
+
 // The wave's share of the chunk's Schur products.  Pairs (ti <= tj) of 16-row tiles in row-major order of the upper triangle;
 // the wave with (wave + chunk) % 4 == w takes q = w, w + 4, ...: the waves with one pair more change from chunk to chunk, so that
 // the four matrix pipes of a CU see the same load.  NP: the pairs this call sums (accumulators are register arrays: static),
@@ -331,12 +432,19 @@ __global__ __launch_bounds__(kThreads, 3) void k_track_sweep_dense(SweepArgs A) 
   const int nb = ncam * (ncam + 1) / 2;
   {
     const int NT = (6 * ncam + 15) >> 4;
-    const int npairs = NT * (NT + 1) / 2;
-    const int wq = ((tid >> 6) + cix) & 3;
-    const int mine = npairs > wq ? (npairs - wq + 3) >> 2 : 0;  // this wave's pairs: at most 2 up to three row tiles (8 cameras), 6 beyond
-    int done = 0;
-    for (; done + 2 <= mine; done += 2) schur_pairs<2>(s_W, s_rec, s_U, slab, tid, cix, npt, ncam, NT, ncopy, cstride, A.dbg, done);
-    if (done < mine) schur_pairs<1>(s_W, s_rec, s_U, slab, tid, cix, npt, ncam, NT, ncopy, cstride, A.dbg, done);
+    static_assert(4 * 28 * 36 <= kObsMax * kWStride, "four copies of the blocks of 7 cameras must fit the Z rows");
+    if (ncam <= 7 && ncam > 0 && !(A.dbg & 32)) {  // (workgroup-uniform: the barriers inside are safe)
+      if (NT == 1) schur_units<1>(s_W, s_rec, s_U, slab, tid, npt, ncam, ncopy, cstride, A.dbg);
+      else if (NT == 2) schur_units<2>(s_W, s_rec, s_U, slab, tid, npt, ncam, ncopy, cstride, A.dbg);
+      else schur_units<3>(s_W, s_rec, s_U, slab, tid, npt, ncam, ncopy, cstride, A.dbg);
+    } else {
+      const int npairs = NT * (NT + 1) / 2;
+      const int wq = ((tid >> 6) + cix) & 3;
+      const int mine = npairs > wq ? (npairs - wq + 3) >> 2 : 0;  // this wave's pairs: at most 2 up to three row tiles (8 cameras), 6 beyond
+      int done = 0;
+      for (; done + 2 <= mine; done += 2) schur_pairs<2>(s_W, s_rec, s_U, slab, tid, cix, npt, ncam, NT, ncopy, cstride, A.dbg, done);
+      if (done < mine) schur_pairs<1>(s_W, s_rec, s_U, slab, tid, cix, npt, ncam, NT, ncopy, cstride, A.dbg, done);
+    }
   }
 
   MPSFM_STAMP(7);
