@@ -5,6 +5,7 @@
 // ba_kernels.hip / dense_chol.hip; this file only orders launches and takes the accept/reject
 // decisions from a handful of scalars.
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -26,6 +27,7 @@
 #include <sched.h>
 
 #include "common.h"
+#include "devbuild.h"
 
 namespace mpsfm {
 
@@ -449,6 +451,8 @@ struct mpsfm_ba_handle {
   RedDest* d_red_dests = nullptr;   // slab reduction: destination parts and their sources
   int32_t* d_red_srcs = nullptr;
   int n_red_dests = 0;
+  int64_t n_red_srcs = 0, n_chunk_cams = 0;  // table sizes (diagnostics: mpsfm_debug_table)
+  bool built_on_device = false;
   LongHdr* d_lhdr = nullptr;
   double* d_wl = nullptr;
   int64_t red_count = 0, sblk_count = 0, sblk_blocks = 0;
@@ -782,11 +786,33 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   h->loss.reproj_type = P->reproj_loss_type; h->loss.reproj_a = P->reproj_loss_scale;
   h->loss.reproj_mag = P->reproj_loss_magnitude; h->loss.depth_type = P->depth_loss_type;
 
+  // -- Device-side table build (build_dev.hip) where it applies: one rank, at most kIndexMaxSlots non-constant cameras, no
+  //    landmark with more blocks than a chunk holds, no chunk for the general kernel.  Stage 1 runs here (block counts per camera,
+  //    blocks grouped by landmark, camera graph); the rest of this function then skips its host phases.  MPSFM_DEV_BUILD=0: host.
+  bool dev = false;
+  std::unique_ptr<DevBuilder> devb;
+  DevBuildOut DB;
+  std::vector<uint64_t> dev_gbits;
+  std::vector<int32_t> prov((size_t)std::max(nc, 1), -1);  // provisional slots of the graph stage: the non-constant cameras in order
+  int nprov = 0;
+  for (int i = 0; i < nc; ++i) if (!P->pose_const[i]) prov[(size_t)i] = nprov++;
+  const int dev_words = (nprov + 63) / 64;
   // -- cameras of the reduced program: not constant and referenced by a residual block (any shard)
   std::vector<double> cnt(nc + 1, 0.0);
-  for (int64_t i = 0; i < P->n_obs; ++i) cnt[P->obs_cam[i]] += 1.0;
-  for (int64_t i = 0; i < P->n_dobs; ++i) cnt[P->dobs_cam[i]] += 1.0;
-  if (int rc = allreduce_host(h, cnt.data(), nc)) return rc;
+  const bool dev_wanted = !sharded(h) && nprov <= kIndexMaxSlots && nc <= 8192 && P->n_obs + P->n_dobs > 0 &&
+                          !(std::getenv("MPSFM_DEV_BUILD") && std::atoi(std::getenv("MPSFM_DEV_BUILD")) == 0) &&
+                          !(std::getenv("MPSFM_CHOL_GRAPH") && std::atoi(std::getenv("MPSFM_CHOL_GRAPH")) == 0);
+  if (dev_wanted) {
+    devb.reset(new DevBuilder());
+    int64_t max_blocks = 0;
+    if (int rc = devb->stage1(P, h->stream, prov, nprov, cnt, dev_gbits, dev_words, &max_blocks)) return rc;
+    dev = max_blocks <= kObsMax;  // longer block lists may be long tracks: host build
+    lap("device stage 1 (upload, group, graph)");
+  } else {
+    for (int64_t i = 0; i < P->n_obs; ++i) cnt[P->obs_cam[i]] += 1.0;
+    for (int64_t i = 0; i < P->n_dobs; ++i) cnt[P->dobs_cam[i]] += 1.0;
+    if (int rc = allreduce_host(h, cnt.data(), nc)) return rc;
+  }
   h->cam_slot_h.assign(nc, -1);
   std::vector<double> cmask((size_t)nc * 6, 0.0);
   h->ncv = 0;
@@ -825,7 +851,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   const int mparts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (P->n_obs + P->n_dobs) / 32768));  // starting threads only pays above ~100 k blocks
   std::vector<MergePart> mp((size_t)mparts);
   // Phase A (host threads over landmark ranges): the blocks of every landmark side by side (counting sort).
-  run_parts(mparts, [&](int t, int nparts) {
+  if (!dev) run_parts(mparts, [&](int t, int nparts) {
     MergePart& M = mp[(size_t)t];
     M.p0 = (int)((int64_t)npu * t / nparts); M.p1 = (int)((int64_t)npu * (t + 1) / nparts);
     const int p0 = M.p0, np_loc = M.p1 - M.p0;
@@ -860,7 +886,23 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if (use_graph) {
     graph.init(ncv_real);
     std::vector<std::vector<uint64_t>> gb((size_t)mparts);
-    run_parts(mparts, [&](int t, int) {
+    if (dev) {
+      // the device's graph speaks provisional slots (all non-constant cameras); cameras without blocks have no slot and no edges
+      std::vector<int32_t> nat_of_prov((size_t)std::max(nprov, 1), -1);
+      for (int i = 0; i < nc; ++i) if (prov[(size_t)i] >= 0) nat_of_prov[(size_t)prov[(size_t)i]] = slot[(size_t)i];
+      for (int a = 0; a < nprov; ++a) {
+        const int na = nat_of_prov[(size_t)a];
+        for (int w = 0; w < dev_words; ++w) {
+          uint64_t m = dev_gbits[(size_t)a * dev_words + w];
+          while (m) {
+            const int b = w * 64 + __builtin_ctzll(m);
+            m &= m - 1;
+            const int nb = nat_of_prov[(size_t)b];
+            if (na >= 0 && nb >= 0) graph.set(na, nb);
+          }
+        }
+      }
+    } else run_parts(mparts, [&](int t, int) {
       const MergePart& M = mp[(size_t)t];
       std::vector<uint64_t>& B = gb[(size_t)t];
       B.assign(graph.bits.size(), 0);
@@ -879,7 +921,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
           }
       }
     });
-    for (const auto& B : gb) for (size_t w = 0; w < B.size(); ++w) graph.bits[w] |= B[w];
+    if (!dev) for (const auto& B : gb) for (size_t w = 0; w < B.size(); ++w) graph.bits[w] |= B[w];
     if (sharded(h)) {
       // union over the ranks through the sum exchange (pack_graph / unpack_graph); the number of ranks comes from the
       // exchange itself (a hook may come without world_size)
@@ -909,6 +951,71 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     for (int i = 0; i < ncv_real; ++i) h->nat_slot[(size_t)i] = i;
   }
 
+  // tables both builds hand to the tail of this function
+  std::vector<ChunkHdr> chunks;
+  std::vector<int32_t> chunk_cams;
+  HostBuf<int32_t> rec_cam, rec_pt;
+  std::vector<int32_t> pt_rec_start;
+  std::vector<uint32_t> blk_desc, ents;          // Schur pairs grouped by destination block, per chunk
+  std::vector<int32_t> blk_ent_start;
+  HostBuf<uint32_t> rec_meta;
+  std::vector<uint16_t> pt_kv;
+  HostBuf<double> rec_xy, rec_d, rec_m, rec_a;
+  int64_t nrec_total = 0;
+  int64_t nblk_reduced = 0;
+  double nvarpts = 0;
+  std::vector<LongHdr> lhdr;
+  int64_t wl_rows = 0;
+  std::vector<int32_t> fx_cam, fx_pt; std::vector<uint32_t> fx_meta; std::vector<double> fx_xy, fx_d, fx_m, fx_a;
+  if (dev) {
+    const bool dense_on = !(std::getenv("MPSFM_SWEEP_DENSE") && std::atoi(std::getenv("MPSFM_SWEEP_DENSE")) == 0);
+    const int rc2 = devb->stage2(slot, dense_on, DB);
+    if (rc2 < 0) return rc2;
+    bool general = false;
+    if (rc2 == 0) for (const ChunkHdr& H : DB.chunks) general = general || !H.dense;
+    if (rc2 == MPSFM_DEVBUILD_FALLBACK || general) {
+      // long tracks, or chunks for the general kernel (their pair tables are host work): the host phases run after all — Phase A
+      // first, which was skipped
+      DB.release();
+      dev = false;
+      run_parts(mparts, [&](int t, int nparts) {
+        MergePart& M = mp[(size_t)t];
+        M.p0 = (int)((int64_t)npu * t / nparts); M.p1 = (int)((int64_t)npu * (t + 1) / nparts);
+        const int p0 = M.p0, np_loc = M.p1 - M.p0;
+        std::vector<int64_t>& pstart = M.pstart;
+        pstart.assign((size_t)np_loc + 1, 0);
+        for (int64_t i = 0; i < P->n_obs; ++i) { const unsigned q = (unsigned)(P->obs_pt[i] - p0); if (q < (unsigned)np_loc) pstart[q + 1]++; }
+        for (int64_t i = 0; i < P->n_dobs; ++i) { const unsigned q = (unsigned)(P->dobs_pt[i] - p0); if (q < (unsigned)np_loc) pstart[q + 1]++; }
+        for (int q = 0; q < np_loc; ++q) pstart[q + 1] += pstart[q];
+        M.blks.alloc((size_t)pstart[np_loc]);
+        std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
+        for (int64_t i = 0; i < P->n_obs; ++i) {
+          const unsigned q = (unsigned)(P->obs_pt[i] - p0);
+          if (q >= (unsigned)np_loc) continue;
+          M.blks[(size_t)fill[q]++] = Blk{P->obs_cam[i], 0, 0, i};
+        }
+        for (int64_t i = 0; i < P->n_dobs; ++i) {
+          const unsigned q = (unsigned)(P->dobs_pt[i] - p0);
+          if (q >= (unsigned)np_loc) continue;
+          M.blks[(size_t)fill[q]++] = Blk{P->dobs_cam[i], 0, 1, i};  // depths were validated by stage 1
+        }
+      });
+      lap("device build not applicable: host phases");
+    } else {
+      chunks.swap(DB.chunks); chunk_cams.swap(DB.chunk_cams);
+      h->perm.swap(DB.order);
+      h->np = DB.np; h->np_chunked = DB.np_chunked; h->nfixed = DB.nfixed;
+      h->nblocks_total = P->n_obs + P->n_dobs;
+      nrec_total = DB.nrec; nblk_reduced = DB.nblk_reduced; nvarpts = DB.nvarpts;
+      if (nrec_total > (int64_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "more than 2^31 records on one device");
+      h->nchunks = (int)chunks.size();
+      h->nlong = 0; h->nrec = nrec_total; h->nblocks_reduced = nblk_reduced;
+      h->nblocks_global = (double)h->nblocks_total; h->nblocks_reduced_global = (double)nblk_reduced; h->nvarpts_global = nvarpts;
+      blk_ent_start.assign(chunks.size(), 0);  // the per-chunk sentinels of the (empty) pair tables
+      lap("device stage 2 (order, chunks, records)");
+    }
+  }
+  if (!dev) {
   // Phase B (the same host threads): every landmark's blocks ordered by (final) camera slot, a reprojection and a depth
   // block of one (camera, landmark) pair merged into one record.
   run_parts(mparts, [&](int t, int) {
@@ -1078,18 +1185,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   // -- chunking.  Pass 1 (sequential, greedy): cut the ordered landmarks into chunks and collect each chunk's
   //    sorted camera slots.  Pass 2 (host threads over contiguous chunk ranges): records, local camera
   //    indices and the block-major Schur pair tables of every chunk.
-  std::vector<ChunkHdr> chunks;
-  std::vector<int32_t> chunk_cams;
-  HostBuf<int32_t> rec_cam, rec_pt;
-  std::vector<int32_t> pt_rec_start((size_t)h->np + 1, 0);
-  std::vector<uint32_t> blk_desc, ents;          // Schur pairs grouped by destination block, per chunk
-  std::vector<int32_t> blk_ent_start;
-  HostBuf<uint32_t> rec_meta;
-  std::vector<uint16_t> pt_kv((size_t)h->np + 1, 0xffff);
-  HostBuf<double> rec_xy, rec_d, rec_m, rec_a;
-  int64_t nrec_total = 0;
-  int64_t nblk_reduced = 0;
-  double nvarpts = 0;
+  pt_rec_start.assign((size_t)h->np + 1, 0);
+  pt_kv.assign((size_t)h->np + 1, 0xffff);
   {
     std::vector<int64_t> rec_off((size_t)h->np_chunked + 1, 0);  // first record of every chunked landmark
     for (int64_t k = 0; k < h->np_chunked; ++k) rec_off[(size_t)k + 1] = rec_off[(size_t)k] + (prec[order[k] + 1] - prec[order[k]]);
@@ -1287,8 +1384,6 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   lap("concatenate pair tables");
   if (ents.size() > (size_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "too many Schur pairs for 32-bit entry offsets");
   h->nchunks = (int)chunks.size();
-  std::vector<LongHdr> lhdr;
-  int64_t wl_rows = 0;
   {
     size_t w = h->np_chunked > 0 ? (size_t)(pt_rec_start[(size_t)h->np_chunked - 1] + (prec[order[h->np_chunked - 1] + 1] - prec[order[h->np_chunked - 1]])) : 0;
     for (int64_t k = h->np_chunked; k < h->np_chunked + n_long; ++k) {
@@ -1321,6 +1416,12 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     if (int rc = allreduce_host(h, tot, 3)) return rc;
     h->nblocks_global = tot[0]; h->nblocks_reduced_global = tot[1]; h->nvarpts_global = tot[2];
   }
+  // -- fixed records (landmark index re-ordered)
+  for (size_t i = 0; i < fixed.size(); ++i) {
+    fx_cam.push_back(fixed[i].cam); fx_pt.push_back(inv[fixed_pt[i]]); fx_meta.push_back(fixed[i].flags);
+    fx_xy.push_back(fixed[i].u); fx_xy.push_back(fixed[i].v); fx_d.push_back(fixed[i].d); fx_m.push_back(fixed[i].m); fx_a.push_back(fixed[i].a);
+  }
+  }  // host phases
 
   lap("chunks + pair tables");
   if (h->opt.verbose >= 2 && !chunks.empty()) {
@@ -1489,15 +1590,9 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       }
     }
     h->n_red_dests = (int)red_dests.size();
+    h->n_red_srcs = (int64_t)red_srcs.size(); h->n_chunk_cams = (int64_t)chunk_cams.size();
   }
   lap("slab reduction tables");
-
-  // -- fixed records (landmark index re-ordered)
-  std::vector<int32_t> fx_cam, fx_pt; std::vector<uint32_t> fx_meta; std::vector<double> fx_xy, fx_d, fx_m, fx_a;
-  for (size_t i = 0; i < fixed.size(); ++i) {
-    fx_cam.push_back(fixed[i].cam); fx_pt.push_back(inv[fixed_pt[i]]); fx_meta.push_back(fixed[i].flags);
-    fx_xy.push_back(fixed[i].u); fx_xy.push_back(fixed[i].v); fx_d.push_back(fixed[i].d); fx_m.push_back(fixed[i].m); fx_a.push_back(fixed[i].a);
-  }
 
   // -- upload
   int rc = 0;
@@ -1509,6 +1604,16 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_cam_slot, h->cam_slot_h))) return rc;
   if ((rc = dev_upload(&h->d_chunks, chunks))) return rc;
   if ((rc = dev_upload(&h->d_chunk_cams, chunk_cams))) return rc;
+  h->built_on_device = dev;
+  if (dev) {  // the device build's tables are where they belong
+    h->d_rec_cam = DB.d_rec_cam; h->d_rec_pt = DB.d_rec_pt; h->d_rec_meta = DB.d_rec_meta; h->d_rec_xy = DB.d_rec_xy; h->d_rec_d = DB.d_rec_d;
+    h->d_rec_m = DB.d_rec_m; h->d_rec_a = DB.d_rec_a; h->d_pt_rec_start = DB.d_pt_rec_start; h->d_pt_kv = DB.d_pt_kv;
+    h->d_fx_cam = DB.d_fx_cam; h->d_fx_pt = DB.d_fx_pt; h->d_fx_meta = DB.d_fx_meta; h->d_fx_xy = DB.d_fx_xy; h->d_fx_d = DB.d_fx_d; h->d_fx_m = DB.d_fx_m;
+    h->d_fx_a = DB.d_fx_a;
+    DB.d_rec_cam = DB.d_rec_pt = DB.d_pt_rec_start = DB.d_fx_cam = DB.d_fx_pt = nullptr; DB.d_rec_meta = DB.d_fx_meta = nullptr; DB.d_pt_kv = nullptr;
+    DB.d_rec_xy = DB.d_rec_d = DB.d_rec_m = DB.d_rec_a = DB.d_fx_xy = DB.d_fx_d = DB.d_fx_m = DB.d_fx_a = nullptr;
+    DB.release();  // the device copies of chunks / camera lists: the host copies (slab offsets added) are uploaded above
+  } else {
   if ((rc = dev_upload(&h->d_rec_cam, rec_cam))) return rc;
   if ((rc = dev_upload(&h->d_rec_pt, rec_pt))) return rc;
   if ((rc = dev_upload(&h->d_rec_meta, rec_meta))) return rc;
@@ -1517,15 +1622,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_rec_m, rec_m))) return rc;
   if ((rc = dev_upload(&h->d_rec_a, rec_a))) return rc;
   if ((rc = dev_upload(&h->d_pt_rec_start, pt_rec_start))) return rc;
-  if ((rc = dev_upload(&h->d_lhdr, lhdr))) return rc;
-  if ((rc = dev_alloc(&h->d_wl, (size_t)std::max<int64_t>(wl_rows, 1) * 18))) return rc;
-  if ((rc = dev_upload(&h->d_blk_desc, blk_desc))) return rc;
-  if ((rc = dev_upload(&h->d_blk_ent_start, blk_ent_start))) return rc;
-  if ((rc = dev_upload(&h->d_ents, ents))) return rc;
   if ((rc = dev_upload(&h->d_pt_kv, pt_kv))) return rc;
-  if ((rc = dev_upload(&h->d_red_dests, red_dests))) return rc;
-  if ((rc = dev_upload(&h->d_red_srcs, red_srcs))) return rc;
-  if ((rc = dev_alloc(&h->d_slab, (size_t)std::max<int64_t>(slab_units, 1) * 18))) return rc;
   if ((rc = dev_upload(&h->d_fx_cam, fx_cam))) return rc;
   if ((rc = dev_upload(&h->d_fx_pt, fx_pt))) return rc;
   if ((rc = dev_upload(&h->d_fx_meta, fx_meta))) return rc;
@@ -1533,6 +1630,15 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_fx_d, fx_d))) return rc;
   if ((rc = dev_upload(&h->d_fx_m, fx_m))) return rc;
   if ((rc = dev_upload(&h->d_fx_a, fx_a))) return rc;
+  }
+  if ((rc = dev_upload(&h->d_lhdr, lhdr))) return rc;
+  if ((rc = dev_alloc(&h->d_wl, (size_t)std::max<int64_t>(wl_rows, 1) * 18))) return rc;
+  if ((rc = dev_upload(&h->d_blk_desc, blk_desc))) return rc;
+  if ((rc = dev_upload(&h->d_blk_ent_start, blk_ent_start))) return rc;
+  if ((rc = dev_upload(&h->d_ents, ents))) return rc;
+  if ((rc = dev_upload(&h->d_red_dests, red_dests))) return rc;
+  if ((rc = dev_upload(&h->d_red_srcs, red_srcs))) return rc;
+  if ((rc = dev_alloc(&h->d_slab, (size_t)std::max<int64_t>(slab_units, 1) * 18))) return rc;
 
   if ((rc = drain_uploads())) return rc;
   lap("upload tables");
@@ -2161,6 +2267,51 @@ int mpsfm_debug_read_trace(mpsfm_ba_handle* h, long long* out, int64_t count) {
   HIP_TRY(hipMemcpyAsync(out, h->d_diagV, sizeof(long long) * (size_t)count, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
+}
+
+// Diagnostics / tests (tests/test_gpu_devbuild.py): table `which` of the handle copied to `out` (at most `cap` bytes); returns the
+// table's size in bytes, or a negative error code.  which: 0 chunk headers, 1 chunk cameras, 2 rec_cam, 3 rec_pt, 4 rec_meta, 5 rec_xy,
+// 6 rec_d, 7 rec_m, 8 rec_a, 9 pt_rec_start, 10 pt_kv, 11 fx_cam, 12 fx_pt, 13 fx_meta, 14 fx_xy, 15 fx_d, 16 fx_m, 17 fx_a,
+// 18 landmark order (host), 19 reduction destinations, 20 reduction sources, 21 camera slots (host), 22: 1 byte, built on the device?
+int64_t mpsfm_debug_table(mpsfm_ba_handle* h, int32_t which, void* out, int64_t cap) {
+  if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
+  const void* src = nullptr;
+  int64_t bytes = 0;
+  bool host = false;
+  const int64_t nr = h->nrec, np1 = h->np + 1, nf = h->nfixed;
+  switch (which) {
+    case 0: src = h->d_chunks; bytes = (int64_t)sizeof(ChunkHdr) * h->nchunks; break;
+    case 1: src = h->d_chunk_cams; bytes = 4 * h->n_chunk_cams; break;
+    case 2: src = h->d_rec_cam; bytes = 4 * nr; break;
+    case 3: src = h->d_rec_pt; bytes = 4 * nr; break;
+    case 4: src = h->d_rec_meta; bytes = 4 * nr; break;
+    case 5: src = h->d_rec_xy; bytes = 16 * nr; break;
+    case 6: src = h->d_rec_d; bytes = 8 * nr; break;
+    case 7: src = h->d_rec_m; bytes = 8 * nr; break;
+    case 8: src = h->d_rec_a; bytes = 8 * nr; break;
+    case 9: src = h->d_pt_rec_start; bytes = 4 * np1; break;
+    case 10: src = h->d_pt_kv; bytes = 2 * np1; break;
+    case 11: src = h->d_fx_cam; bytes = 4 * nf; break;
+    case 12: src = h->d_fx_pt; bytes = 4 * nf; break;
+    case 13: src = h->d_fx_meta; bytes = 4 * nf; break;
+    case 14: src = h->d_fx_xy; bytes = 16 * nf; break;
+    case 15: src = h->d_fx_d; bytes = 8 * nf; break;
+    case 16: src = h->d_fx_m; bytes = 8 * nf; break;
+    case 17: src = h->d_fx_a; bytes = 8 * nf; break;
+    case 18: src = h->perm.data(); bytes = 4 * (int64_t)h->perm.size(); host = true; break;
+    case 19: src = h->d_red_dests; bytes = (int64_t)sizeof(RedDest) * h->n_red_dests; break;
+    case 20: src = h->d_red_srcs; bytes = 4 * h->n_red_srcs; break;
+    case 21: src = h->cam_slot_h.data(); bytes = 4 * (int64_t)h->cam_slot_h.size(); host = true; break;
+    case 22: { static uint8_t flag; flag = h->built_on_device ? 1 : 0; src = &flag; bytes = 1; host = true; break; }
+    default: return fail(MPSFM_EINVAL, "unknown table");
+  }
+  if (!out || cap < bytes) return bytes;
+  if (bytes == 0) return 0;
+  if (host) { std::memcpy(out, src, (size_t)bytes); return bytes; }
+  if (hipSetDevice(h->device) != hipSuccess) return fail(MPSFM_EHIP, "hipSetDevice failed");
+  if (hipMemcpyAsync(out, src, (size_t)bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return fail(MPSFM_EHIP, "copy failed");
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MPSFM_EHIP, "sync failed");
+  return bytes;
 }
 
 int mpsfm_ba_sweep_parts(mpsfm_ba_handle* h, float ms[3], int64_t info[4]) {

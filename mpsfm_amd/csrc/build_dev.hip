@@ -1,0 +1,626 @@
+// Device-side table build of the bundle-adjustment handle (gfx950): what `build()` in ba_solver.hip does on host threads —
+// residual blocks grouped by landmark, merged into records, landmarks ordered by their camera-slot lists, the greedy chunk cut,
+// the record arrays — as HIP kernels over the caller's raw observation lists.  The reference assembles a NEW problem for every
+// Optimizer.ba() call (mpsfm/sfm/mapper/bundle_adjustment.py:184, 285-293), so the tables are on the critical path of every call.
+//
+// Two stages around the camera order (the graph / nested dissection / factorisation plan stay on the host, 0.3-0.5 ms):
+//   stage 1  upload the observation lists; count blocks per landmark and per camera; scan; scatter the blocks to their
+//            landmark; camera graph (bit matrix, test-before-atomicOr)                              -> host: graph, counts
+//   stage 2  per landmark: sort its blocks by (slot, camera, kind, source), count the merged records, flags (long / heavy),
+//            sort key; landmark order by two stable radix sorts (rocPRIM) + a stable class sort; record offsets by scan; the
+//            chunk cut — one WAVE per segment, the open chunk's camera set a 4096-bit set spread over the 64 lanes —; chunk
+//            headers and camera lists compacted; the record arrays written in place                  -> host: chunks, camera lists,
+//            landmark order, counters
+// The results are the tables of the host build BIT FOR BIT (tests/test_gpu_devbuild.py compares every table of two handles),
+// except `rec_d` = log(depth), where the device's log may differ from libm's in the last place.
+//
+// Not covered (the caller falls back to the host threads): landmark-sharded runs (the exchanges of the build are host values),
+// more than 4096 variable cameras (no camera graph), a landmark with more blocks than a chunk holds (long tracks).
+#include <cstring>
+#include <string.h>
+
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <climits>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "devbuild.h"
+
+namespace mpsfm {
+extern thread_local std::string g_err;
+int staged_upload(void* dst, const void* src, size_t bytes);
+int staged_drain();
+static int dfail(int code, const std::string& m) { g_err = m; return code; }
+#define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return dfail(MPSFM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+namespace {
+constexpr int kT = 256;
+constexpr int kLmSlots = 32;  // distinct variable slots cached per landmark for the chunk cut (longer lists are re-read from the blocks)
+
+struct LmInfo {  // per landmark (caller's index), written by k_sortmerge
+  int32_t nrec, nfix, kv, distinct;
+  uint32_t flags;  // 1 long, 2 heavy, 4 dup, 8 bad depth
+  uint32_t pad;
+  uint64_t k1, k2;
+};
+enum { LM_LONG = 1, LM_HEAVY = 2, LM_DUP = 4, LM_BAD = 8 };
+
+__global__ __launch_bounds__(kT) void k_count(int64_t n_obs, int64_t n_dobs, const int32_t* obs_cam, const int32_t* obs_pt, const int32_t* dobs_cam,
+                                              const int32_t* dobs_pt, const double* dobs_depth, int nc, int np, int32_t* cnt_pt, int32_t* cnt_cam, int32_t* err) {
+  extern __shared__ int32_t s_cam[];
+  for (int i = threadIdx.x; i < nc; i += kT) s_cam[i] = 0;
+  __syncthreads();
+  const int64_t n = n_obs + n_dobs;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) {
+    int cam, pt;
+    if (i < n_obs) { cam = obs_cam[i]; pt = obs_pt[i]; }
+    else {
+      cam = dobs_cam[i - n_obs]; pt = dobs_pt[i - n_obs];
+      if (!(dobs_depth[i - n_obs] > 0.0)) atomicOr(err, 1);
+    }
+    atomicAdd(&cnt_pt[pt], 1);
+    atomicAdd(&s_cam[cam], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc; i += kT) if (s_cam[i]) atomicAdd(&cnt_cam[i], s_cam[i]);
+}
+
+__global__ __launch_bounds__(kT) void k_scatter(int64_t n_obs, int64_t n_dobs, const int32_t* obs_cam, const int32_t* obs_pt, const int32_t* dobs_cam,
+                                                const int32_t* dobs_pt, const int32_t* pstart, int32_t* fill, int32_t* blk_cam, uint32_t* blk_src) {
+  const int64_t n = n_obs + n_dobs;
+  for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kT) {
+    int cam, pt;
+    uint32_t src;
+    if (i < n_obs) { cam = obs_cam[i]; pt = obs_pt[i]; src = (uint32_t)i; }
+    else { cam = dobs_cam[i - n_obs]; pt = dobs_pt[i - n_obs]; src = (uint32_t)(i - n_obs) | 0x80000000u; }
+    const int at = pstart[pt] + atomicAdd(&fill[pt], 1);
+    blk_cam[at] = cam; blk_src[at] = src;
+  }
+}
+
+// camera graph: two variable cameras are adjacent when a variable landmark has blocks of both (caller's "natural" slots)
+__global__ __launch_bounds__(kT) void k_graph(int np, const int32_t* pstart, const int32_t* blk_cam, const uint8_t* pt_const, const int32_t* nat,
+                                              int words, unsigned long long* bits) {
+  const int p = blockIdx.x * kT + threadIdx.x;
+  if (p >= np || pt_const[p]) return;
+  const int ps = pstart[p], n = pstart[p + 1] - ps;
+  for (int i = 1; i < n; ++i) {
+    const int si = nat[blk_cam[ps + i]];
+    if (si < 0) continue;
+    for (int j = 0; j < i; ++j) {
+      const int sj = nat[blk_cam[ps + j]];
+      if (sj < 0 || sj == si) continue;
+      unsigned long long* w1 = &bits[(size_t)si * words + (sj >> 6)];
+      unsigned long long* w2 = &bits[(size_t)sj * words + (si >> 6)];
+      const unsigned long long b1 = 1ull << (sj & 63), b2 = 1ull << (si & 63);
+      if (!(*w1 & b1)) atomicOr(w1, b1);
+      if (!(*w2 & b2)) atomicOr(w2, b2);
+    }
+  }
+}
+
+// The merge of a landmark's sorted blocks into records, shared by the counting and the writing pass: per camera the k-th
+// reprojection block and the k-th depth block form record k (host build(), "Phase B").  emit(cam, slot, flags, reproj source or
+// -1, depth source or -1).
+template <class Emit>
+__device__ __forceinline__ void merge_blocks(int ps, int n, const int32_t* blk_cam, const int32_t* blk_key, const uint32_t* blk_src, Emit&& emit) {
+  int it = 0;
+  while (it < n) {
+    const int cam = blk_cam[ps + it];
+    int je = it;
+    while (je < n && blk_cam[ps + je] == cam) ++je;
+    int mid = it;
+    while (mid < je && !(blk_src[ps + mid] & 0x80000000u)) ++mid;
+    const int nr = mid - it, nd = je - mid;
+    const int key = blk_key[ps + it];
+    const int slot = key == INT_MAX ? -1 : key;
+    for (int k = 0; k < max(nr, nd); ++k) {
+      uint32_t flags = 0;
+      int64_t sr = -1, sd = -1;
+      if (k < nr) { flags |= kRecHasReproj; sr = (int64_t)blk_src[ps + it + k]; }
+      if (k < nd) { flags |= kRecHasDepth; sd = (int64_t)(blk_src[ps + mid + k] & 0x7fffffffu); }
+      emit(cam, slot, flags, sr, sd);
+    }
+    it = je;
+  }
+}
+
+__global__ __launch_bounds__(kT) void k_sortmerge(int np, const int32_t* pstart, int32_t* blk_cam, int32_t* blk_key, uint32_t* blk_src, const int32_t* slot_of_cam,
+                                                  const uint8_t* pt_const, int dense_on, LmInfo* info, uint16_t* lm_slots) {
+  const int p = blockIdx.x * kT + threadIdx.x;
+  if (p >= np) return;
+  const int ps = pstart[p], n = pstart[p + 1] - ps;
+  LmInfo I{};
+  if (n == 0) { info[p] = I; return; }
+  for (int i = 0; i < n; ++i) { const int s = slot_of_cam[blk_cam[ps + i]]; blk_key[ps + i] = s < 0 ? INT_MAX : s; }
+  // insertion sort by (key, camera, kind, source): `source` carries the kind in its top bit, so (kind, source) is one compare
+  for (int i = 1; i < n; ++i) {
+    const int k = blk_key[ps + i], c = blk_cam[ps + i];
+    const uint32_t s = blk_src[ps + i];
+    int j = i - 1;
+    while (j >= 0) {
+      const int kj = blk_key[ps + j], cj = blk_cam[ps + j];
+      const uint32_t sj = blk_src[ps + j];
+      const bool less = k != kj ? k < kj : (c != cj ? c < cj : s < sj);
+      if (!less) break;
+      blk_key[ps + j + 1] = kj; blk_cam[ps + j + 1] = cj; blk_src[ps + j + 1] = sj;
+      --j;
+    }
+    blk_key[ps + j + 1] = k; blk_cam[ps + j + 1] = c; blk_src[ps + j + 1] = s;
+  }
+  const bool cpt = pt_const[p] != 0;
+  int nrec = 0, nfix = 0, kv = 0, distinct = 0, last = -2;
+  bool dup = false;
+  uint64_t key[2] = {0, 0};
+  int nkey = 0;
+  merge_blocks(ps, n, blk_cam, blk_key, blk_src, [&](int, int slot, uint32_t, int64_t, int64_t) {
+    if (slot < 0 && cpt) { ++nfix; return; }
+    if (nkey < 6) {  // the first six record slots (16 bits each; constant cameras and slots beyond 65534 saturate)
+      const uint64_t sk = slot >= 0 ? (uint64_t)min(slot, 0xfffe) : 0xffffull;
+      key[nkey / 4] = (key[nkey / 4] << 16) | sk;
+      ++nkey;
+    }
+    ++nrec;
+    if (slot >= 0) {
+      ++kv;
+      if (slot != last) { if (distinct < kLmSlots) lm_slots[(size_t)p * kLmSlots + distinct] = (uint16_t)slot; ++distinct; last = slot; }
+      else dup = true;
+    }
+  });
+  for (; nkey < 6; ++nkey) key[nkey / 4] = (key[nkey / 4] << 16) | 0xffffull;
+  key[1] = (key[1] << 32) | (uint64_t)(uint32_t)nrec;
+  I.nrec = nrec; I.nfix = nfix; I.kv = kv; I.distinct = distinct; I.k1 = key[0]; I.k2 = key[1];
+  if (nrec > kObsMax || distinct > kLocalCamsMax) I.flags |= LM_LONG;
+  if (!dense_on || distinct > kDenseCams || (dup && !cpt)) I.flags |= LM_HEAVY;
+  if (dup) I.flags |= LM_DUP;
+  info[p] = I;
+}
+
+// candidates of the order: landmarks with records, ascending; and the landmarks that only fixed blocks reference
+__global__ __launch_bounds__(kT) void k_flags(int np, const LmInfo* info, int32_t* has_rec, int32_t* fix_only, int32_t* nfix) {
+  const int p = blockIdx.x * kT + threadIdx.x;
+  if (p >= np) return;
+  has_rec[p] = info[p].nrec > 0; fix_only[p] = info[p].nrec == 0 && info[p].nfix > 0; nfix[p] = info[p].nfix;
+}
+__global__ __launch_bounds__(kT) void k_candidates(int np, const LmInfo* info, const int32_t* pos, unsigned long long* k2, int32_t* idx, int32_t* cand) {
+  const int p = blockIdx.x * kT + threadIdx.x;
+  if (p >= np || info[p].nrec <= 0) return;
+  const int i = pos[p];
+  k2[i] = info[p].k2; idx[i] = i; cand[i] = p;
+}
+__global__ __launch_bounds__(kT) void k_gather_k1(int n, const int32_t* idx, const int32_t* cand, const LmInfo* info, unsigned long long* k1, int32_t* pout) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const int p = cand[idx[i]];
+  k1[i] = info[p].k1; pout[i] = p;
+}
+__global__ __launch_bounds__(kT) void k_classes(int n, const int32_t* order1, const LmInfo* info, uint32_t* cls, int32_t* counts) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = info[order1[i]].flags;
+  const uint32_t c = (f & LM_LONG) ? 2u : ((f & LM_HEAVY) ? 1u : 0u);
+  cls[i] = c;
+  atomicAdd(&counts[c], 1);
+}
+__global__ __launch_bounds__(kT) void k_append_fixed_only(int np, const int32_t* fix_only, const int32_t* fpos, int base, int32_t* order) {
+  const int p = blockIdx.x * kT + threadIdx.x;
+  if (p < np && fix_only[p]) order[base + fpos[p]] = p;
+}
+__global__ __launch_bounds__(kT) void k_inverse(int n, const int32_t* order, const LmInfo* info, int32_t* inv, int32_t* nrec_k, int n_withrec) {
+  const int k = blockIdx.x * kT + threadIdx.x;
+  if (k >= n) return;
+  const int p = order[k];
+  inv[p] = k;
+  nrec_k[k] = k < n_withrec ? info[p].nrec : 0;
+}
+
+// ---- the greedy chunk cut: one wave per segment ---------------------------------------------------------------------------
+struct TmpChunk { int32_t first, npt, ncam, cam0; };  // segment-local camera offset
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__global__ __launch_bounds__(64) void k_cut(int np_chunked, int nseg, const int32_t* order, const LmInfo* info, const uint16_t* lm_slots, const int32_t* pstart,
+                                            const int32_t* blk_key, const int32_t* rec_off, TmpChunk* tmp_chunks, int32_t* tmp_cams, int32_t* lm_chunk,
+                                            int32_t* seg_nchunks, int32_t* seg_ncams) {
+  const int sidx = blockIdx.x, lane = threadIdx.x;
+  const int64_t k0 = (int64_t)np_chunked * sidx / nseg, k1 = (int64_t)np_chunked * (sidx + 1) / nseg;
+  __shared__ uint16_t s_slots[64][kLmSlots];
+  __shared__ int32_t s_ns[64], s_rp[64], s_hv[64], s_p[64];
+  unsigned long long cur = 0;  // this lane's 64 slots of the open chunk's camera set
+  int64_t c_first = k0;
+  int c_nrec = 0, nchunks = 0, ncams = 0;
+  int c_hv = 0;
+  auto close_chunk = [&](int64_t end_pt) {
+    if (end_pt == c_first) return;
+    const int mine = __popcll(cur);
+    int incl = mine;  // inclusive scan over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    const int total = __shfl(incl, 63, 64);
+    int at = ncams + incl - mine;  // segment-local
+    unsigned long long m = cur;
+    int32_t* out = tmp_cams + rec_off[k0];  // capacity: a chunk has at most as many cameras as records
+    while (m) { const int b = __builtin_ctzll(m); m &= m - 1; out[at++] = lane * 64 + b; }
+    if (lane == 0) tmp_chunks[k0 + nchunks] = TmpChunk{(int32_t)c_first, (int32_t)(end_pt - c_first), total, ncams};
+    ncams += total; ++nchunks;
+    cur = 0; c_first = end_pt; c_nrec = 0;
+  };
+  for (int64_t base = k0; base < k1; base += 64) {
+    const int64_t k = base + lane;
+    __syncthreads();
+    if (k < k1) {
+      const int p = order[k];
+      const LmInfo I = info[p];
+      s_p[lane] = p; s_ns[lane] = I.distinct; s_rp[lane] = I.nrec; s_hv[lane] = (I.flags & LM_HEAVY) ? 1 : 0;
+      const uint4* src = reinterpret_cast<const uint4*>(lm_slots + (size_t)p * kLmSlots);
+      uint4* dst = reinterpret_cast<uint4*>(&s_slots[lane][0]);
+      if (I.distinct > 0) {
+#pragma unroll
+        for (int q = 0; q < kLmSlots * 2 / 16; ++q) dst[q] = src[q];
+      }
+    }
+    __syncthreads();
+    const int nb = (int)min<int64_t>(64, k1 - base);
+    for (int j = 0; j < nb; ++j) {
+      const int64_t kk = base + j;
+      const int ns = s_ns[j], rp = s_rp[j], hv = s_hv[j];
+      unsigned long long m = 0;  // the landmark's camera set
+      if (ns <= kLmSlots) {
+        for (int t = 0; t < ns; ++t) { const int s = s_slots[j][t]; if (lane == (s >> 6)) m |= 1ull << (s & 63); }
+      } else {  // a long camera list: from the sorted block keys
+        const int p = s_p[j], ps = pstart[p], n = pstart[p + 1] - ps;
+        for (int t = 0; t < n; ++t) { const int s = blk_key[ps + t]; if (s != INT_MAX && lane == (s >> 6)) m |= 1ull << (s & 63); }
+      }
+      const bool subset = __ballot((m & ~cur) != 0) == 0;
+      int nuni = 0;
+      if (!subset) nuni = wave_sum_i(__popcll(cur | m));
+      else nuni = -1;  // not needed: the set does not grow (its size was admissible when it was formed)
+      const bool first_of_chunk = kk == c_first;
+      if (first_of_chunk) c_hv = hv;
+      const bool too_big = (c_nrec + rp > kObsMax) || (kk - c_first + 1 > (hv ? kPtsMax : kDensePts)) || (nuni > (hv ? kLocalCamsMax : kDenseCams)) || (hv != c_hv);
+      if (!first_of_chunk && too_big) {
+        close_chunk(kk);
+        cur = m; c_hv = hv;
+      } else if (!subset) {
+        cur |= m;
+      }
+      c_nrec += rp;
+      if (lane == 0) lm_chunk[kk] = nchunks;
+    }
+  }
+  close_chunk(k1);
+  if (lane == 0) { seg_nchunks[sidx] = nchunks; seg_ncams[sidx] = ncams; }
+}
+
+__global__ __launch_bounds__(64) void k_seg_scan(int nseg, const int32_t* seg_nchunks, const int32_t* seg_ncams, int32_t* cbase, int32_t* cambase) {
+  if (threadIdx.x == 0) {
+    int a = 0, b = 0;
+    for (int s = 0; s < nseg; ++s) { cbase[s] = a; cambase[s] = b; a += seg_nchunks[s]; b += seg_ncams[s]; }
+    cbase[nseg] = a; cambase[nseg] = b;
+  }
+}
+__global__ __launch_bounds__(kT) void k_chunks_final(int np_chunked, int nseg, const TmpChunk* tmp_chunks, const int32_t* tmp_cams, const int32_t* rec_off,
+                                                     const int32_t* order, const LmInfo* info, const int32_t* cbase, const int32_t* cambase, ChunkHdr* chunks,
+                                                     int32_t* chunk_cams) {
+  const int sidx = blockIdx.x;
+  const int64_t k0 = (int64_t)np_chunked * sidx / nseg;
+  const int nch = cbase[sidx + 1] - cbase[sidx];
+  for (int c = threadIdx.x; c < nch; c += kT) {
+    const TmpChunk T = tmp_chunks[k0 + c];
+    ChunkHdr H{};
+    H.rec0 = rec_off[T.first]; H.nrec = rec_off[T.first + T.npt] - rec_off[T.first];
+    H.pt0 = T.first; H.npt = T.npt; H.cam0 = cambase[sidx] + T.cam0; H.ncam = T.ncam;
+    H.dense = (info[order[T.first]].flags & LM_HEAVY) ? 0 : 1;
+    chunks[cbase[sidx] + c] = H;
+  }
+  const int ncam = cambase[sidx + 1] - cambase[sidx];
+  const int32_t* src = tmp_cams + rec_off[k0];
+  for (int i = threadIdx.x; i < ncam; i += kT) chunk_cams[cambase[sidx] + i] = src[i];
+}
+
+// ---- the record arrays -------------------------------------------------------------------------------------------------------
+struct RecOut {
+  int32_t* rec_cam; int32_t* rec_pt; uint32_t* rec_meta; double* rec_xy; double* rec_d; double* rec_m; double* rec_a;
+  int32_t* pt_rec_start; uint16_t* pt_kv;
+  int32_t* fx_cam; int32_t* fx_pt; uint32_t* fx_meta; double* fx_xy; double* fx_d; double* fx_m; double* fx_a;
+};
+__global__ __launch_bounds__(kT) void k_records(int n_order, int np_chunked, int n_withrec, int nrec_total, const int32_t* order, const LmInfo* info,
+                                                const int32_t* pstart, const int32_t* blk_cam, const int32_t* blk_key, const uint32_t* blk_src, const int32_t* rec_off,
+                                                const int32_t* fix_off, const int32_t* lm_chunk, const int32_t* cbase, int nseg, const ChunkHdr* chunks,
+                                                const int32_t* chunk_cams, const uint8_t* pt_const, const double* obs_xy, const double* dobs_depth,
+                                                const double* dobs_mag, const double* dobs_par, const double* shift, RecOut O, unsigned long long* counters,
+                                                int32_t* err) {
+  const int k = blockIdx.x * kT + threadIdx.x;
+  if (k >= n_order) return;
+  const int p = order[k];
+  const LmInfo I = info[p];
+  const int ps = pstart[p], n = pstart[p + 1] - ps;
+  const bool cpt = pt_const[p] != 0;
+  const bool chunked = k < np_chunked;
+  int w = k < n_withrec ? rec_off[k] : nrec_total;
+  O.pt_rec_start[k] = w;
+  ChunkHdr H{};
+  const int32_t* cams = nullptr;
+  if (chunked) {
+    int s = min((int)(((int64_t)k * nseg) / max(np_chunked, 1)), nseg - 1);  // the segment whose [k0, k1) holds k
+    while (s > 0 && (int64_t)np_chunked * s / nseg > k) --s;
+    while (s + 1 < nseg && (int64_t)np_chunked * (s + 1) / nseg <= k) ++s;
+    H = chunks[cbase[s] + lm_chunk[k]];
+    cams = chunk_cams + H.cam0;
+  }
+  int f = fix_off[p];
+  unsigned long long nblk = 0;
+  merge_blocks(ps, n, blk_cam, blk_key, blk_src, [&](int cam, int slot, uint32_t flags, int64_t sr, int64_t sd) {
+    double u = 0.0, v = 0.0, d = 1.0, m = 0.0, a = 1.0;
+    if (sr >= 0) { u = obs_xy[2 * sr]; v = obs_xy[2 * sr + 1]; }
+    if (sd >= 0) {
+      double b = 0.0, s = 0.0;
+      if (shift) { b = shift[2 * cam]; s = shift[2 * cam + 1]; }
+      d = dobs_depth[sd] * exp(s) + b; m = dobs_mag[sd]; a = dobs_par[sd];
+      if (!(d > 0.0)) atomicOr(err, 2);
+      d = log(d);  // the residual is log Z - log d: the records carry log d
+    }
+    if (slot < 0 && cpt) {
+      O.fx_cam[f] = cam; O.fx_pt[f] = k; O.fx_meta[f] = flags; O.fx_xy[2 * f] = u; O.fx_xy[2 * f + 1] = v; O.fx_d[f] = d; O.fx_m[f] = m; O.fx_a[f] = a;
+      ++f;
+      return;
+    }
+    uint32_t lcam = kLcamConst;
+    if (slot >= 0 && chunked) {
+      int lo = 0, hi = H.ncam;  // lower bound in the chunk's sorted camera list
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (cams[mid] < slot) lo = mid + 1; else hi = mid; }
+      lcam = (uint32_t)lo;
+    }
+    O.rec_cam[w] = cam; O.rec_pt[w] = k;
+    O.rec_meta[w] = lcam | ((uint32_t)(k - H.pt0) << 8) | flags;
+    O.rec_xy[2 * (size_t)w] = u; O.rec_xy[2 * (size_t)w + 1] = v; O.rec_d[w] = d; O.rec_m[w] = m; O.rec_a[w] = a;
+    nblk += ((flags & kRecHasReproj) ? 1 : 0) + ((flags & kRecHasDepth) ? 1 : 0);
+    ++w;
+  });
+  O.pt_kv[k] = (!cpt && k < n_withrec) ? (uint16_t)I.kv : (uint16_t)0xffff;
+  if (nblk) atomicAdd(&counters[0], nblk);
+  if (!cpt && k < n_withrec) atomicAdd(&counters[1], 1ull);
+}
+
+// rocPRIM calls with their temporary storage from the caching allocator
+template <class F>
+int with_temp(F&& f) {
+  size_t bytes = 0;
+  if (f(nullptr, bytes) != hipSuccess) return dfail(MPSFM_EHIP, "rocPRIM size query failed");
+  void* tmp = cached_malloc(std::max<size_t>(bytes, 16));
+  if (!tmp) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  const hipError_t e = f(tmp, bytes);
+  cached_free(tmp);  // stream-ordered use: the block goes back to the cache, handed out again only to later work of this thread's streams
+  return e == hipSuccess ? 0 : dfail(MPSFM_EHIP, "rocPRIM call failed");
+}
+}  // namespace
+
+struct DevBuilder::Impl {
+  hipStream_t s = nullptr;
+  int nc = 0, np = 0;
+  int64_t n_obs = 0, n_dobs = 0, nblk = 0;
+  std::vector<void*> blocks;  // everything to give back
+  template <class T> T* alloc(size_t n) { T* p = (T*)cached_malloc(std::max<size_t>(n, 1) * sizeof(T)); if (p) blocks.push_back(p); return p; }
+  // raw input
+  int32_t *obs_cam = nullptr, *obs_pt = nullptr, *dobs_cam = nullptr, *dobs_pt = nullptr;
+  double *obs_xy = nullptr, *dobs_depth = nullptr, *dobs_mag = nullptr, *dobs_par = nullptr, *shift = nullptr;
+  uint8_t* pt_const = nullptr;
+  // grouping
+  int32_t *cnt_pt = nullptr, *cnt_cam = nullptr, *pstart = nullptr, *fill = nullptr, *blk_cam = nullptr, *blk_key = nullptr, *err = nullptr;
+  uint32_t* blk_src = nullptr;
+  unsigned long long* bits = nullptr;
+  int32_t* nat = nullptr;
+};
+
+DevBuilder::DevBuilder() : m(new Impl()) {}
+DevBuilder::~DevBuilder() {
+  if (m->s) (void)hipStreamSynchronize(m->s);  // the blocks go back to a process-wide cache
+  for (void* p : m->blocks) cached_free(p);
+  delete m;
+}
+
+int DevBuilder::stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std::vector<int32_t>& nat_slot, int ncv_real, std::vector<double>& cam_counts,
+                       std::vector<uint64_t>& graph_bits, int graph_words, int64_t* max_blocks_per_landmark) {
+  Impl& M = *m;
+  M.s = stream; M.nc = P->n_cams; M.np = P->n_pts; M.n_obs = P->n_obs; M.n_dobs = P->n_dobs; M.nblk = P->n_obs + P->n_dobs;
+  if (M.nblk > (int64_t)INT_MAX / 2) return dfail(MPSFM_EUNSUPPORTED, "device build: more than 2^30 residual blocks");
+  const size_t no = (size_t)M.n_obs, nd = (size_t)M.n_dobs, np = (size_t)M.np, nc = (size_t)M.nc;
+  M.obs_cam = M.alloc<int32_t>(no); M.obs_pt = M.alloc<int32_t>(no); M.obs_xy = M.alloc<double>(2 * no);
+  M.dobs_cam = M.alloc<int32_t>(nd); M.dobs_pt = M.alloc<int32_t>(nd); M.dobs_depth = M.alloc<double>(nd); M.dobs_mag = M.alloc<double>(nd);
+  M.dobs_par = M.alloc<double>(nd); M.pt_const = M.alloc<uint8_t>(np); M.nat = M.alloc<int32_t>(nc);
+  M.cnt_pt = M.alloc<int32_t>(np + 1); M.cnt_cam = M.alloc<int32_t>(nc); M.pstart = M.alloc<int32_t>(np + 1); M.fill = M.alloc<int32_t>(np + 1);
+  M.blk_cam = M.alloc<int32_t>((size_t)M.nblk); M.blk_key = M.alloc<int32_t>((size_t)M.nblk); M.blk_src = M.alloc<uint32_t>((size_t)M.nblk);
+  M.err = M.alloc<int32_t>(4);
+  M.bits = M.alloc<unsigned long long>((size_t)std::max(ncv_real, 1) * (size_t)std::max(graph_words, 1));
+  if (P->shift_logscale) M.shift = M.alloc<double>(2 * nc);
+  for (void* p : M.blocks) if (!p) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  int rc = 0;
+  if (no) {
+    if ((rc = staged_upload(M.obs_cam, P->obs_cam, 4 * no))) return rc;
+    if ((rc = staged_upload(M.obs_pt, P->obs_pt, 4 * no))) return rc;
+    if ((rc = staged_upload(M.obs_xy, P->obs_xy, 16 * no))) return rc;
+  }
+  if (nd) {
+    if ((rc = staged_upload(M.dobs_cam, P->dobs_cam, 4 * nd))) return rc;
+    if ((rc = staged_upload(M.dobs_pt, P->dobs_pt, 4 * nd))) return rc;
+    if ((rc = staged_upload(M.dobs_depth, P->dobs_depth, 8 * nd))) return rc;
+    if ((rc = staged_upload(M.dobs_mag, P->dobs_magnitude, 8 * nd))) return rc;
+    if ((rc = staged_upload(M.dobs_par, P->dobs_param, 8 * nd))) return rc;
+  }
+  if (np && (rc = staged_upload(M.pt_const, P->pt_const, np))) return rc;
+  if (nc && (rc = staged_upload(M.nat, nat_slot.data(), 4 * nc))) return rc;
+  if (M.shift && (rc = staged_upload(M.shift, P->shift_logscale, 16 * nc))) return rc;
+  if ((rc = staged_drain())) return rc;
+  DB_TRY(hipMemsetAsync(M.cnt_pt, 0, 4 * (np + 1), M.s));
+  DB_TRY(hipMemsetAsync(M.cnt_cam, 0, 4 * std::max<size_t>(nc, 1), M.s));
+  DB_TRY(hipMemsetAsync(M.fill, 0, 4 * (np + 1), M.s));
+  DB_TRY(hipMemsetAsync(M.err, 0, 16, M.s));
+  DB_TRY(hipMemsetAsync(M.bits, 0, 8 * (size_t)std::max(ncv_real, 1) * (size_t)std::max(graph_words, 1), M.s));
+  const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (M.nblk + kT - 1) / kT));
+  hipLaunchKernelGGL(k_count, dim3(grid), dim3(kT), (size_t)4 * std::max(M.nc, 1), M.s, M.n_obs, M.n_dobs, M.obs_cam, M.obs_pt, M.dobs_cam, M.dobs_pt, M.dobs_depth,
+                     M.nc, M.np, M.cnt_pt, M.cnt_cam, M.err);
+  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, M.cnt_pt, M.pstart, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(kT), 0, M.s, M.n_obs, M.n_dobs, M.obs_cam, M.obs_pt, M.dobs_cam, M.dobs_pt, M.pstart, M.fill, M.blk_cam, M.blk_src);
+  if (ncv_real > 0 && np)
+    hipLaunchKernelGGL(k_graph, dim3((unsigned)((np + kT - 1) / kT)), dim3(kT), 0, M.s, M.np, M.pstart, M.blk_cam, M.pt_const, M.nat, graph_words, M.bits);
+  // to the host: block counts per camera, the graph, the error flags, the longest block list
+  std::vector<int32_t> cc(std::max<size_t>(nc, 1)), er(4), cp(np + 1);
+  DB_TRY(hipMemcpyAsync(cc.data(), M.cnt_cam, 4 * nc, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipMemcpyAsync(er.data(), M.err, 16, hipMemcpyDeviceToHost, M.s));
+  graph_bits.assign((size_t)std::max(ncv_real, 0) * (size_t)graph_words, 0);
+  if (!graph_bits.empty()) DB_TRY(hipMemcpyAsync(graph_bits.data(), M.bits, 8 * graph_bits.size(), hipMemcpyDeviceToHost, M.s));
+  // the longest block list: a max-reduction over the counts (rocPRIM)
+  int32_t* d_max = M.alloc<int32_t>(1);
+  if (!d_max) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::reduce(t, b, M.cnt_pt, d_max, 0, np + 1, rocprim::maximum<int32_t>(), M.s); }))) return rc;
+  int32_t mx = 0;
+  DB_TRY(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipStreamSynchronize(M.s));
+  if (er[0] & 1) return dfail(MPSFM_EINVAL, "depth prior must be positive");
+  cam_counts.assign(nc + 1, 0.0);
+  for (size_t i = 0; i < nc; ++i) cam_counts[i] = (double)cc[i];
+  *max_blocks_per_landmark = mx;
+  return 0;
+}
+
+int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, DevBuildOut& out) {
+  Impl& M = *m;
+  const size_t np = (size_t)M.np, nc = (size_t)M.nc;
+  int rc = 0;
+  int32_t* d_slot = M.alloc<int32_t>(nc);
+  LmInfo* info = M.alloc<LmInfo>(np);
+  uint16_t* lm_slots = M.alloc<uint16_t>(np * kLmSlots + 8);
+  int32_t *has_rec = M.alloc<int32_t>(np + 1), *fix_only = M.alloc<int32_t>(np + 1), *nfix = M.alloc<int32_t>(np + 1);
+  int32_t *pos = M.alloc<int32_t>(np + 1), *fpos = M.alloc<int32_t>(np + 1), *fix_off = M.alloc<int32_t>(np + 1);
+  if (!d_slot || !info || !lm_slots || !has_rec || !fix_only || !nfix || !pos || !fpos || !fix_off) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  if (nc && (rc = staged_upload(d_slot, slot_of_cam.data(), 4 * nc))) return rc;
+  if ((rc = staged_drain())) return rc;
+  const unsigned gnp = (unsigned)std::max<size_t>(1, (np + kT - 1) / kT);
+  if (np) hipLaunchKernelGGL(k_sortmerge, dim3(gnp), dim3(kT), 0, M.s, M.np, M.pstart, M.blk_cam, M.blk_key, M.blk_src, d_slot, M.pt_const, dense_on ? 1 : 0, info, lm_slots);
+  if (np) hipLaunchKernelGGL(k_flags, dim3(gnp), dim3(kT), 0, M.s, M.np, info, has_rec, fix_only, nfix);
+  DB_TRY(hipMemsetAsync(has_rec + np, 0, 4, M.s));
+  DB_TRY(hipMemsetAsync(fix_only + np, 0, 4, M.s));
+  DB_TRY(hipMemsetAsync(nfix + np, 0, 4, M.s));
+  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, has_rec, pos, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, fix_only, fpos, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, nfix, fix_off, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  int32_t tot[3] = {0, 0, 0};
+  DB_TRY(hipMemcpyAsync(&tot[0], pos + np, 4, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipMemcpyAsync(&tot[1], fpos + np, 4, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipMemcpyAsync(&tot[2], fix_off + np, 4, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipStreamSynchronize(M.s));
+  const int n_withrec = tot[0], n_fixonly = tot[1], n_fixed = tot[2];
+  const int n_order = n_withrec + n_fixonly;
+  out.np = n_order; out.nfixed = n_fixed;
+  // ---- landmark order: (k1, k2, p) ascending by two stable radix sorts, then the stable class sort (normal | heavy | long)
+  const size_t nw = (size_t)std::max(n_withrec, 1);
+  unsigned long long *k2 = M.alloc<unsigned long long>(nw), *k2s = M.alloc<unsigned long long>(nw), *k1 = M.alloc<unsigned long long>(nw), *k1s = M.alloc<unsigned long long>(nw);
+  int32_t *idx = M.alloc<int32_t>(nw), *idx1 = M.alloc<int32_t>(nw), *cand = M.alloc<int32_t>(nw), *pg = M.alloc<int32_t>(nw), *order1 = M.alloc<int32_t>(nw);
+  uint32_t *cls = M.alloc<uint32_t>(nw), *cls_s = M.alloc<uint32_t>(nw);
+  int32_t* order = M.alloc<int32_t>((size_t)std::max(n_order, 1));
+  int32_t* counts = M.alloc<int32_t>(4);
+  if (!k2 || !k2s || !k1 || !k1s || !idx || !idx1 || !cand || !pg || !order1 || !cls || !cls_s || !order || !counts) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  DB_TRY(hipMemsetAsync(counts, 0, 16, M.s));
+  int32_t cl[4] = {0, 0, 0, 0};
+  if (n_withrec > 0) {
+    const unsigned gw = (unsigned)((n_withrec + kT - 1) / kT);
+    hipLaunchKernelGGL(k_candidates, dim3(gnp), dim3(kT), 0, M.s, M.np, info, pos, k2, idx, cand);
+    if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::radix_sort_pairs(t, b, k2, k2s, idx, idx1, (size_t)n_withrec, 0, 64, M.s); }))) return rc;
+    hipLaunchKernelGGL(k_gather_k1, dim3(gw), dim3(kT), 0, M.s, n_withrec, idx1, cand, info, k1, pg);
+    if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::radix_sort_pairs(t, b, k1, k1s, pg, order1, (size_t)n_withrec, 0, 64, M.s); }))) return rc;
+    hipLaunchKernelGGL(k_classes, dim3(gw), dim3(kT), 0, M.s, n_withrec, order1, info, cls, counts);
+    if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::radix_sort_pairs(t, b, cls, cls_s, order1, order, (size_t)n_withrec, 0, 2, M.s); }))) return rc;
+    DB_TRY(hipMemcpyAsync(cl, counts, 16, hipMemcpyDeviceToHost, M.s));
+  }
+  if (n_fixonly > 0) hipLaunchKernelGGL(k_append_fixed_only, dim3(gnp), dim3(kT), 0, M.s, M.np, fix_only, fpos, n_withrec, order);
+  int32_t* inv = M.alloc<int32_t>(np + 1);
+  int32_t* nrec_k = M.alloc<int32_t>((size_t)n_order + 1);
+  int32_t* rec_off = M.alloc<int32_t>((size_t)n_order + 2);
+  if (!inv || !nrec_k || !rec_off) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  if (n_order > 0) hipLaunchKernelGGL(k_inverse, dim3((unsigned)((n_order + kT - 1) / kT)), dim3(kT), 0, M.s, n_order, order, info, inv, nrec_k, n_withrec);
+  DB_TRY(hipMemsetAsync(nrec_k + n_order, 0, 4, M.s));
+  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, nrec_k, rec_off, 0, (size_t)n_order + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  int32_t nrec_total = 0;
+  DB_TRY(hipMemcpyAsync(&nrec_total, rec_off + n_order, 4, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipStreamSynchronize(M.s));
+  const int n_long = cl[2];
+  const int np_chunked = n_withrec - n_long;
+  out.np_chunked = np_chunked; out.n_long = n_long; out.nrec = nrec_total;
+  if (n_long > 0) return MPSFM_DEVBUILD_FALLBACK;  // long tracks: the host build handles them
+  // ---- chunk cut
+  const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(64, np_chunked / 4096));
+  TmpChunk* tmp_chunks = M.alloc<TmpChunk>((size_t)std::max(np_chunked, 1));
+  int32_t* tmp_cams = M.alloc<int32_t>((size_t)std::max(nrec_total, 1));
+  int32_t* lm_chunk = M.alloc<int32_t>((size_t)std::max(np_chunked, 1));
+  int32_t *seg_nch = M.alloc<int32_t>(65), *seg_ncam = M.alloc<int32_t>(65), *cbase = M.alloc<int32_t>(66), *cambase = M.alloc<int32_t>(66);
+  if (!tmp_chunks || !tmp_cams || !lm_chunk || !seg_nch || !seg_ncam || !cbase || !cambase) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  int32_t hb[2][66];
+  std::memset(hb, 0, sizeof(hb));
+  if (np_chunked > 0) {
+    hipLaunchKernelGGL(k_cut, dim3(nseg), dim3(64), 0, M.s, np_chunked, nseg, order, info, lm_slots, M.pstart, M.blk_key, rec_off, tmp_chunks, tmp_cams, lm_chunk, seg_nch, seg_ncam);
+    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(64), 0, M.s, nseg, seg_nch, seg_ncam, cbase, cambase);
+    DB_TRY(hipMemcpyAsync(hb[0], cbase, 4 * (size_t)(nseg + 1), hipMemcpyDeviceToHost, M.s));
+    DB_TRY(hipMemcpyAsync(hb[1], cambase, 4 * (size_t)(nseg + 1), hipMemcpyDeviceToHost, M.s));
+    DB_TRY(hipStreamSynchronize(M.s));
+  }
+  const int nchunks = hb[0][nseg], ncams = hb[1][nseg];
+  // ---- final tables (owned by the caller from here on)
+  auto own = [&](size_t bytes) { return cached_malloc(std::max<size_t>(bytes, 8)); };
+  const size_t nr = (size_t)std::max(nrec_total, 1), nf = (size_t)std::max(n_fixed, 1), no = (size_t)std::max(n_order, 1);
+  out.d_chunks = (ChunkHdr*)own(sizeof(ChunkHdr) * (size_t)std::max(nchunks, 1));
+  out.d_chunk_cams = (int32_t*)own(4 * (size_t)std::max(ncams, 1));
+  out.d_rec_cam = (int32_t*)own(4 * nr); out.d_rec_pt = (int32_t*)own(4 * nr); out.d_rec_meta = (uint32_t*)own(4 * nr);
+  out.d_rec_xy = (double*)own(16 * nr); out.d_rec_d = (double*)own(8 * nr); out.d_rec_m = (double*)own(8 * nr); out.d_rec_a = (double*)own(8 * nr);
+  out.d_pt_rec_start = (int32_t*)own(4 * (no + 1)); out.d_pt_kv = (uint16_t*)own(2 * (no + 1));
+  out.d_fx_cam = (int32_t*)own(4 * nf); out.d_fx_pt = (int32_t*)own(4 * nf); out.d_fx_meta = (uint32_t*)own(4 * nf);
+  out.d_fx_xy = (double*)own(16 * nf); out.d_fx_d = (double*)own(8 * nf); out.d_fx_m = (double*)own(8 * nf); out.d_fx_a = (double*)own(8 * nf);
+  unsigned long long* counters = M.alloc<unsigned long long>(2);
+  void* all[] = {out.d_chunks, out.d_chunk_cams, out.d_rec_cam, out.d_rec_pt, out.d_rec_meta, out.d_rec_xy, out.d_rec_d, out.d_rec_m, out.d_rec_a, out.d_pt_rec_start,
+                 out.d_pt_kv, out.d_fx_cam, out.d_fx_pt, out.d_fx_meta, out.d_fx_xy, out.d_fx_d, out.d_fx_m, out.d_fx_a, counters};
+  for (void* p : all) if (!p) { out.release(); return dfail(MPSFM_ENOMEM, "hipMalloc failed"); }
+  DB_TRY(hipMemsetAsync(counters, 0, 16, M.s));
+  if (nchunks > 0)
+    hipLaunchKernelGGL(k_chunks_final, dim3(nseg), dim3(kT), 0, M.s, np_chunked, nseg, tmp_chunks, tmp_cams, rec_off, order, info, cbase, cambase, out.d_chunks, out.d_chunk_cams);
+  RecOut O{out.d_rec_cam, out.d_rec_pt, out.d_rec_meta, out.d_rec_xy, out.d_rec_d, out.d_rec_m, out.d_rec_a, out.d_pt_rec_start, out.d_pt_kv,
+           out.d_fx_cam, out.d_fx_pt, out.d_fx_meta, out.d_fx_xy, out.d_fx_d, out.d_fx_m, out.d_fx_a};
+  if (n_order > 0)
+    hipLaunchKernelGGL(k_records, dim3((unsigned)((n_order + kT - 1) / kT)), dim3(kT), 0, M.s, n_order, np_chunked, n_withrec, nrec_total, order, info, M.pstart, M.blk_cam,
+                       M.blk_key, M.blk_src, rec_off, fix_off, lm_chunk, cbase, nseg, out.d_chunks, out.d_chunk_cams, M.pt_const, M.obs_xy, M.dobs_depth, M.dobs_mag,
+                       M.dobs_par, M.shift, O, counters, M.err);
+  // the sentinel entry of pt_rec_start / pt_kv
+  DB_TRY(hipMemcpyAsync(out.d_pt_rec_start + n_order, &nrec_total, 4, hipMemcpyHostToDevice, M.s));
+  const uint16_t kv_none = 0xffff;
+  DB_TRY(hipMemcpyAsync(out.d_pt_kv + n_order, &kv_none, 2, hipMemcpyHostToDevice, M.s));
+  // ---- to the host: chunk headers, camera lists, the landmark order, counters
+  out.chunks.resize((size_t)nchunks); out.chunk_cams.resize((size_t)ncams); out.order.resize((size_t)n_order);
+  unsigned long long hc[2] = {0, 0};
+  int32_t er[4] = {0, 0, 0, 0};
+  if (nchunks) DB_TRY(hipMemcpyAsync(out.chunks.data(), out.d_chunks, sizeof(ChunkHdr) * (size_t)nchunks, hipMemcpyDeviceToHost, M.s));
+  if (ncams) DB_TRY(hipMemcpyAsync(out.chunk_cams.data(), out.d_chunk_cams, 4 * (size_t)ncams, hipMemcpyDeviceToHost, M.s));
+  if (n_order) DB_TRY(hipMemcpyAsync(out.order.data(), order, 4 * (size_t)n_order, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipMemcpyAsync(er, M.err, 16, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipStreamSynchronize(M.s));
+  if (er[0] & 2) { out.release(); return dfail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive"); }
+  out.nblk_reduced = (int64_t)hc[0]; out.nvarpts = (double)hc[1];
+  return 0;
+}
+
+void DevBuildOut::release() {
+  void* all[] = {d_chunks, d_chunk_cams, d_rec_cam, d_rec_pt, d_rec_meta, d_rec_xy, d_rec_d, d_rec_m, d_rec_a, d_pt_rec_start, d_pt_kv,
+                 d_fx_cam, d_fx_pt, d_fx_meta, d_fx_xy, d_fx_d, d_fx_m, d_fx_a};
+  for (void* p : all) cached_free(p);
+  d_chunks = nullptr; d_chunk_cams = nullptr; d_rec_cam = d_rec_pt = nullptr; d_rec_meta = nullptr; d_rec_xy = d_rec_d = d_rec_m = d_rec_a = nullptr;
+  d_pt_rec_start = nullptr; d_pt_kv = nullptr; d_fx_cam = d_fx_pt = nullptr; d_fx_meta = nullptr; d_fx_xy = d_fx_d = d_fx_m = d_fx_a = nullptr;
+}
+
+}  // namespace mpsfm

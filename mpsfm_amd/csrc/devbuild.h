@@ -1,0 +1,45 @@
+// Device-side table build (build_dev.hip), called from build() in ba_solver.hip.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "common.h"
+
+namespace mpsfm {
+
+constexpr int MPSFM_DEVBUILD_FALLBACK = 1;  // stage2: the problem needs the host build (long tracks); nothing was produced
+
+struct DevBuildOut {
+  // device tables, owned by the receiver (cached_malloc blocks)
+  ChunkHdr* d_chunks = nullptr;
+  int32_t *d_chunk_cams = nullptr, *d_rec_cam = nullptr, *d_rec_pt = nullptr, *d_pt_rec_start = nullptr, *d_fx_cam = nullptr, *d_fx_pt = nullptr;
+  uint32_t *d_rec_meta = nullptr, *d_fx_meta = nullptr;
+  uint16_t* d_pt_kv = nullptr;
+  double *d_rec_xy = nullptr, *d_rec_d = nullptr, *d_rec_m = nullptr, *d_rec_a = nullptr, *d_fx_xy = nullptr, *d_fx_d = nullptr, *d_fx_m = nullptr, *d_fx_a = nullptr;
+  // host copies of the small tables the rest of build() works on
+  std::vector<ChunkHdr> chunks;
+  std::vector<int32_t> chunk_cams, order;
+  int64_t np = 0, np_chunked = 0, n_long = 0, nrec = 0, nfixed = 0, nblk_reduced = 0;
+  double nvarpts = 0;
+  void release();
+};
+
+class DevBuilder {
+ public:
+  DevBuilder();
+  ~DevBuilder();
+  DevBuilder(const DevBuilder&) = delete;
+  DevBuilder& operator=(const DevBuilder&) = delete;
+  // uploads the observation lists, groups the blocks by landmark, returns the blocks per camera, the camera graph over the caller's
+  // ("natural") slots and the longest block list of a landmark
+  int stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std::vector<int32_t>& nat_slot, int ncv_real, std::vector<double>& cam_counts,
+             std::vector<uint64_t>& graph_bits, int graph_words, int64_t* max_blocks_per_landmark);
+  // with the final camera slots: landmark order, chunk cut, record arrays.  Returns 0, MPSFM_DEVBUILD_FALLBACK or an error code.
+  int stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, DevBuildOut& out);
+
+ private:
+  struct Impl;
+  Impl* m;
+};
+
+}  // namespace mpsfm

@@ -1,0 +1,94 @@
+"""The device-side table build (csrc/build_dev.hip) against the host-thread build it replaces (`build()` in csrc/ba_solver.hip):
+every table of two handles created from the same problem — one with MPSFM_DEV_BUILD=0 — compared bit for bit (rec_d = log depth:
+within 2 ulp, the device's log is not libm's), then the solves compared."""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from mpsfm_amd import capi
+from mpsfm_amd.synthetic import local_window, make_scene
+
+pytestmark = pytest.mark.gpu
+
+TABLES = {0: ("chunks", np.int32), 1: ("chunk_cams", np.int32), 2: ("rec_cam", np.int32), 3: ("rec_pt", np.int32), 4: ("rec_meta", np.uint32),
+          5: ("rec_xy", np.float64), 6: ("rec_d", np.float64), 7: ("rec_m", np.float64), 8: ("rec_a", np.float64), 9: ("pt_rec_start", np.int32),
+          10: ("pt_kv", np.uint16), 11: ("fx_cam", np.int32), 12: ("fx_pt", np.int32), 13: ("fx_meta", np.uint32), 14: ("fx_xy", np.float64),
+          15: ("fx_d", np.float64), 16: ("fx_m", np.float64), 17: ("fx_a", np.float64), 18: ("order", np.int32), 19: ("red_dests", np.int32),
+          20: ("red_srcs", np.int32), 21: ("cam_slot", np.int32), 22: ("built_on_device", np.uint8)}
+
+
+def tables(h):
+    L = capi.lib()
+    L.mpsfm_debug_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    L.mpsfm_debug_table.restype = C.c_int64
+    out = {}
+    for which, (name, dt) in TABLES.items():
+        n = L.mpsfm_debug_table(h._h, which, None, 0)
+        assert n >= 0, name
+        buf = np.zeros(max(n, 1), np.uint8)
+        assert L.mpsfm_debug_table(h._h, which, buf.ctypes.data, n) == n
+        out[name] = buf[:n].view(dt).copy()
+    return out
+
+
+def both(prob, monkeypatch):
+    monkeypatch.setenv("MPSFM_DEV_BUILD", "0")
+    with capi.BAHandle(prob.copy()) as hh:
+        th = tables(hh)
+        hh.reset_state()
+        sh = hh.solve()
+    monkeypatch.delenv("MPSFM_DEV_BUILD")
+    with capi.BAHandle(prob.copy()) as hd:
+        td = tables(hd)
+        hd.reset_state()
+        sd = hd.solve()
+    return th, td, sh, sd
+
+
+def assert_same_tables(th, td):
+    assert th["built_on_device"][0] == 0 and td["built_on_device"][0] == 1
+    for name in th:
+        if name == "built_on_device":
+            continue
+        a, b = th[name], td[name]
+        assert a.shape == b.shape, name
+        if name in ("rec_d", "fx_d"):
+            assert np.all(np.abs(a - b) <= 4 * np.spacing(np.abs(a))), name
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=name)
+
+
+@pytest.mark.parametrize("ncam,npts,depth,seed", [(50, 20000, False, 0), (24, 9000, True, 3), (60, 30000, True, 4), (6, 300, True, 5)])
+def test_device_build_equals_host_build(monkeypatch, ncam, npts, depth, seed):
+    prob, _ = make_scene(ncam, npts, depth, seed=seed)
+    th, td, sh, sd = both(prob, monkeypatch)
+    assert_same_tables(th, td)
+    assert len(th["chunks"]) > 0 and len(th["red_srcs"]) > 0
+    assert sh["num_iterations"] == sd["num_iterations"] and sh["termination"] == sd["termination"]
+    assert sd["final_cost"] == pytest.approx(sh["final_cost"], rel=1e-10)
+
+
+def test_device_build_with_constant_cameras_points_and_fixed_blocks(monkeypatch):
+    """A local window: constant outside cameras (records with lcam 255), constant landmarks, blocks with both constant (the fixed
+    list), cameras without any block, landmarks without any block."""
+    base, _ = make_scene(30, 6000, True, seed=11)
+    prob = local_window(base, list(range(8, 14)), ref_cam=10)[0]
+    prob.pt_const[::7] = 1
+    prob.pose_const[-1] = 0  # a variable camera that may have no block at all
+    th, td, sh, sd = both(prob, monkeypatch)
+    assert_same_tables(th, td)
+    assert len(th["fx_cam"]) > 0 and (th["rec_meta"] & 0xff == 255).any()
+    assert sd["final_cost"] == pytest.approx(sh["final_cost"], rel=1e-10) and sh["num_iterations"] == sd["num_iterations"]
+
+
+def test_problems_the_device_build_hands_back(monkeypatch):
+    """Long tracks and landmarks with more than 16 cameras (general chunks) take the host phases; the handle says so and solves."""
+    prob, _ = make_scene(40, 3000, True, seed=2, max_track=40, track_mean=25.0)
+    with capi.BAHandle(prob.copy()) as h:
+        t = tables(h)
+        assert t["built_on_device"][0] == 0
+        s = h.solve()
+    assert s["final_cost"] < s["initial_cost"]
