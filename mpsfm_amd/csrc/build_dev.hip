@@ -26,7 +26,10 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -189,25 +192,46 @@ __global__ __launch_bounds__(kT) void k_flags(int np, const LmInfo* info, int32_
   if (p >= np) return;
   has_rec[p] = info[p].nrec > 0; fix_only[p] = info[p].nrec == 0 && info[p].nfix > 0; nfix[p] = info[p].nfix;
 }
-__global__ __launch_bounds__(kT) void k_candidates(int np, const LmInfo* info, const int32_t* pos, unsigned long long* k2, int32_t* idx, int32_t* cand) {
+// Sort keys.  The host orders the landmarks by (first six record slots, record count, landmark); the same order from keys that hold
+// each slot in `b` bits (b = bits of the slot count; a missing / constant camera becomes the all-ones value, above every slot) and the
+// class (normal | heavy | long) on top, so that ONE stable radix sort over few bits replaces two 64-bit sorts and the class sort:
+//   b <= 9 (up to 511 cameras):  key = class | s0 .. s5 | count  (2 + 6 b + 9 <= 65 - ... bits), one sort
+//   otherwise: kB = s4 | s5 | count first, then kA = class | s0 .. s3 (stable)
+__device__ __forceinline__ unsigned long long pack_slot(unsigned long long s16, int b) { const unsigned long long top = (1ull << b) - 1; return s16 >= top ? top : s16; }
+__global__ __launch_bounds__(kT) void k_candidates(int np, const LmInfo* info, const int32_t* pos, int b, int single, unsigned long long* kA, unsigned long long* kB,
+                                                   int32_t* cand, int32_t* counts) {
   const int p = blockIdx.x * kT + threadIdx.x;
-  if (p >= np || info[p].nrec <= 0) return;
+  const bool valid = p < np && info[min(p, np - 1)].nrec > 0;
+  LmInfo I{};
+  if (valid) I = info[p];
+  const unsigned long long cls = (I.flags & LM_LONG) ? 2ull : ((I.flags & LM_HEAVY) ? 1ull : 0ull);
+  // class counts: one atomic per wave and class (150 k adds to one address take 1.8 ms)
+  for (int c = 0; c < 3; ++c) {
+    const unsigned long long m = __ballot(valid && cls == (unsigned long long)c);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(&counts[c], __popcll(m));
+  }
+  if (!valid) return;
   const int i = pos[p];
-  k2[i] = info[p].k2; idx[i] = i; cand[i] = p;
+  unsigned long long sl[6];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sl[q] = pack_slot((I.k1 >> (16 * (3 - q))) & 0xffffull, b);
+  sl[4] = pack_slot((I.k2 >> 48) & 0xffffull, b); sl[5] = pack_slot((I.k2 >> 32) & 0xffffull, b);
+  const unsigned long long cnt9 = (unsigned long long)min(I.nrec, 511);  // chunked landmarks hold at most kObsMax records; longer ones are in class 2,
+                                                                         // whose internal order the host phases redo anyway
+  if (single) {
+    unsigned long long k = cls;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) k = (k << b) | sl[q];
+    kA[i] = (k << 9) | cnt9;
+  } else {
+    kB[i] = (((sl[4] << b) | sl[5]) << 9) | cnt9;
+    kA[i] = (((((cls << b) | sl[0]) << b | sl[1]) << b | sl[2]) << b) | sl[3];
+  }
+  cand[i] = p;
 }
-__global__ __launch_bounds__(kT) void k_gather_k1(int n, const int32_t* idx, const int32_t* cand, const LmInfo* info, unsigned long long* k1, int32_t* pout) {
+__global__ __launch_bounds__(kT) void k_gather_keys(int n, const int32_t* cand_sorted, const int32_t* pos, const unsigned long long* kA, unsigned long long* kA_g) {
   const int i = blockIdx.x * kT + threadIdx.x;
-  if (i >= n) return;
-  const int p = cand[idx[i]];
-  k1[i] = info[p].k1; pout[i] = p;
-}
-__global__ __launch_bounds__(kT) void k_classes(int n, const int32_t* order1, const LmInfo* info, uint32_t* cls, int32_t* counts) {
-  const int i = blockIdx.x * kT + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t f = info[order1[i]].flags;
-  const uint32_t c = (f & LM_LONG) ? 2u : ((f & LM_HEAVY) ? 1u : 0u);
-  cls[i] = c;
-  atomicAdd(&counts[c], 1);
+  if (i < n) kA_g[i] = kA[pos[cand_sorted[i]]];
 }
 __global__ __launch_bounds__(kT) void k_append_fixed_only(int np, const int32_t* fix_only, const int32_t* fpos, int base, int32_t* order) {
   const int p = blockIdx.x * kT + threadIdx.x;
@@ -228,17 +252,30 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__global__ __launch_bounds__(64) void k_cut(int np_chunked, int nseg, const int32_t* order, const LmInfo* info, const uint16_t* lm_slots, const int32_t* pstart,
+// W = words of a camera set that can hold a bit (slots / 64, rounded up): lanes >= W never hold one.
+__global__ __launch_bounds__(64) void k_cut(int np_chunked, int nseg, int W, const int32_t* order, const LmInfo* info, const uint16_t* lm_slots, const int32_t* pstart,
                                             const int32_t* blk_key, const int32_t* rec_off, TmpChunk* tmp_chunks, int32_t* tmp_cams, int32_t* lm_chunk,
                                             int32_t* seg_nchunks, int32_t* seg_ncams) {
   const int sidx = blockIdx.x, lane = threadIdx.x;
   const int64_t k0 = (int64_t)np_chunked * sidx / nseg, k1 = (int64_t)np_chunked * (sidx + 1) / nseg;
-  __shared__ uint16_t s_slots[64][kLmSlots];
+  extern __shared__ unsigned long long s_mask[];  // [64 landmarks of a batch][W]: their camera sets, built by one lane each
   __shared__ int32_t s_ns[64], s_rp[64], s_hv[64], s_p[64];
   unsigned long long cur = 0;  // this lane's 64 slots of the open chunk's camera set
   int64_t c_first = k0;
   int c_nrec = 0, nchunks = 0, ncams = 0;
   int c_hv = 0;
+  // number of set bits of a set spread over the lanes: only the lanes below W can hold any, and mostly a handful do
+  auto set_size = [&](unsigned long long w) {
+    unsigned long long live = __ballot(w != 0);
+    int n = 0;
+    while (live) {
+      const int l = __builtin_ctzll(live);
+      live &= live - 1;
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), l);
+      n += __popc(lo) + __popc(hi);
+    }
+    return n;
+  };
   auto close_chunk = [&](int64_t end_pt) {
     if (end_pt == c_first) return;
     const int mine = __popcll(cur);
@@ -261,29 +298,24 @@ __global__ __launch_bounds__(64) void k_cut(int np_chunked, int nseg, const int3
       const int p = order[k];
       const LmInfo I = info[p];
       s_p[lane] = p; s_ns[lane] = I.distinct; s_rp[lane] = I.nrec; s_hv[lane] = (I.flags & LM_HEAVY) ? 1 : 0;
-      const uint4* src = reinterpret_cast<const uint4*>(lm_slots + (size_t)p * kLmSlots);
-      uint4* dst = reinterpret_cast<uint4*>(&s_slots[lane][0]);
-      if (I.distinct > 0) {
-#pragma unroll
-        for (int q = 0; q < kLmSlots * 2 / 16; ++q) dst[q] = src[q];
+      unsigned long long* row = s_mask + (size_t)lane * W;
+      for (int w = 0; w < W; ++w) row[w] = 0;
+      if (I.distinct <= kLmSlots) {
+        const uint16_t* sl = lm_slots + (size_t)p * kLmSlots;
+        for (int t = 0; t < I.distinct; ++t) { const int sv = sl[t]; row[sv >> 6] |= 1ull << (sv & 63); }
+      } else {  // a long camera list: from the sorted block keys
+        const int ps = pstart[p], n = pstart[p + 1] - ps;
+        for (int t = 0; t < n; ++t) { const int sv = blk_key[ps + t]; if (sv != INT_MAX) row[sv >> 6] |= 1ull << (sv & 63); }
       }
     }
     __syncthreads();
     const int nb = (int)min<int64_t>(64, k1 - base);
     for (int j = 0; j < nb; ++j) {
       const int64_t kk = base + j;
-      const int ns = s_ns[j], rp = s_rp[j], hv = s_hv[j];
-      unsigned long long m = 0;  // the landmark's camera set
-      if (ns <= kLmSlots) {
-        for (int t = 0; t < ns; ++t) { const int s = s_slots[j][t]; if (lane == (s >> 6)) m |= 1ull << (s & 63); }
-      } else {  // a long camera list: from the sorted block keys
-        const int p = s_p[j], ps = pstart[p], n = pstart[p + 1] - ps;
-        for (int t = 0; t < n; ++t) { const int s = blk_key[ps + t]; if (s != INT_MAX && lane == (s >> 6)) m |= 1ull << (s & 63); }
-      }
+      const int rp = s_rp[j], hv = s_hv[j];
+      const unsigned long long m = lane < W ? s_mask[(size_t)j * W + lane] : 0ull;  // the landmark's camera set
       const bool subset = __ballot((m & ~cur) != 0) == 0;
-      int nuni = 0;
-      if (!subset) nuni = wave_sum_i(__popcll(cur | m));
-      else nuni = -1;  // not needed: the set does not grow (its size was admissible when it was formed)
+      const int nuni = subset ? -1 : set_size(cur | m);  // a subset does not grow the set (its size was admissible when it was formed)
       const bool first_of_chunk = kk == c_first;
       if (first_of_chunk) c_hv = hv;
       const bool too_big = (c_nrec + rp > kObsMax) || (kk - c_first + 1 > (hv ? kPtsMax : kDensePts)) || (nuni > (hv ? kLocalCamsMax : kDenseCams)) || (hv != c_hv);
@@ -299,6 +331,109 @@ __global__ __launch_bounds__(64) void k_cut(int np_chunked, int nseg, const int3
   }
   close_chunk(k1);
   if (lane == 0) { seg_nchunks[sidx] = nchunks; seg_ncams[sidx] = ncams; }
+}
+
+// ---- the chunk cut for camera sets of up to 512 slots (W <= 8 words), without the sequential walk over the landmarks -----------
+// The greedy cut is a chain: a chunk that starts at landmark k ends at next(k), which depends on the landmarks from k on only.  So
+// next(k) is computed for EVERY k in parallel (one thread walks the ~50 landmarks of the chunk that would start there, the camera
+// set in W registers), and the segment's chunks are the chain k0 -> next(k0) -> ... followed by one thread per segment (~75 hops).
+template <int W>
+__global__ __launch_bounds__(kT) void k_lm_masks(int np_chunked, const int32_t* order, const LmInfo* info, const uint16_t* lm_slots, const int32_t* pstart,
+                                                 const int32_t* blk_key, unsigned long long* mask, int32_t* rp, uint8_t* hv) {
+  const int k = blockIdx.x * kT + threadIdx.x;
+  if (k >= np_chunked) return;
+  const int p = order[k];
+  const LmInfo I = info[p];
+  unsigned long long m[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) m[w] = 0;
+  auto set = [&](int sv) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) if ((sv >> 6) == w) m[w] |= 1ull << (sv & 63);
+  };
+  if (I.distinct <= kLmSlots) { for (int t = 0; t < I.distinct; ++t) set(lm_slots[(size_t)p * kLmSlots + t]); }
+  else { const int ps = pstart[p], n = pstart[p + 1] - ps; for (int t = 0; t < n; ++t) { const int sv = blk_key[ps + t]; if (sv != INT_MAX) set(sv); } }
+#pragma unroll
+  for (int w = 0; w < W; ++w) mask[(size_t)k * W + w] = m[w];
+  rp[k] = I.nrec; hv[k] = (I.flags & LM_HEAVY) ? 1 : 0;
+}
+__device__ __forceinline__ int seg_of(int64_t k, int np_chunked, int nseg) {
+  int s = (int)min<int64_t>((k * nseg) / max(np_chunked, 1), nseg - 1);
+  while (s > 0 && (int64_t)np_chunked * s / nseg > k) --s;
+  while (s + 1 < nseg && (int64_t)np_chunked * (s + 1) / nseg <= k) ++s;
+  return s;
+}
+template <int W>
+__global__ __launch_bounds__(kT) void k_next(int np_chunked, int nseg, const unsigned long long* mask, const int32_t* rp, const uint8_t* hv, int32_t* next) {
+  const int k = blockIdx.x * kT + threadIdx.x;
+  if (k >= np_chunked) return;
+  const int64_t k1 = (int64_t)np_chunked * (seg_of(k, np_chunked, nseg) + 1) / nseg;
+  unsigned long long cur[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) cur[w] = 0;
+  int nrec = 0;
+  const int hv0 = hv[k];
+  int64_t kk = k;
+  for (; kk < k1; ++kk) {
+    unsigned long long m[W];
+    bool grow = false;
+    int nuni = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) { m[w] = mask[(size_t)kk * W + w]; grow = grow || (m[w] & ~cur[w]) != 0; nuni += __popcll(cur[w] | m[w]); }
+    if (!grow) nuni = -1;
+    const int r = rp[kk], h = hv[kk];
+    const bool too_big = (nrec + r > kObsMax) || (kk - k + 1 > (h ? kPtsMax : kDensePts)) || (nuni > (h ? kLocalCamsMax : kDenseCams)) || (h != hv0);
+    if (kk > k && too_big) break;
+#pragma unroll
+    for (int w = 0; w < W; ++w) cur[w] |= m[w];
+    nrec += r;
+  }
+  next[k] = (int32_t)kk;
+}
+__global__ __launch_bounds__(64) void k_walk(int np_chunked, int nseg, const int32_t* next, int32_t* starts, int32_t* seg_nchunks) {
+  const int sidx = blockIdx.x * 64 + threadIdx.x;
+  if (sidx >= nseg) return;
+  const int64_t k0 = (int64_t)np_chunked * sidx / nseg, k1 = (int64_t)np_chunked * (sidx + 1) / nseg;
+  int n = 0;
+  for (int64_t c = k0; c < k1; c = next[c]) starts[k0 + n++] = (int32_t)c;
+  seg_nchunks[sidx] = n;
+}
+// one thread per chunk: its camera set, header, and (second pass, after the scan of the camera counts) its sorted camera list
+template <int W>
+__global__ __launch_bounds__(kT) void k_chunk_sets(int nchunks, int np_chunked, int nseg, const int32_t* cbase, const int32_t* starts, const unsigned long long* mask,
+                                                   const int32_t* rec_off, const uint8_t* hv, ChunkHdr* chunks, int32_t* chunk_ncam, unsigned long long* csets) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c >= nchunks) return;
+  int s = 0;  // the segment of chunk c: cbase is ascending, at most 64 entries
+  while (s + 1 < nseg && cbase[s + 1] <= c) ++s;
+  const int i = c - cbase[s];
+  const int64_t k0 = (int64_t)np_chunked * s / nseg, k1 = (int64_t)np_chunked * (s + 1) / nseg;
+  const int first = starts[k0 + i], end = (c + 1 < cbase[s + 1]) ? starts[k0 + i + 1] : (int)k1;
+  unsigned long long u[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) u[w] = 0;
+  for (int k = first; k < end; ++k)
+#pragma unroll
+    for (int w = 0; w < W; ++w) u[w] |= mask[(size_t)k * W + w];
+  int n = 0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) { n += __popcll(u[w]); csets[(size_t)c * W + w] = u[w]; }
+  ChunkHdr H{};
+  H.rec0 = rec_off[first]; H.nrec = rec_off[end] - rec_off[first]; H.pt0 = first; H.npt = end - first; H.ncam = n; H.dense = hv[first] ? 0 : 1;
+  chunks[c] = H;
+  chunk_ncam[c] = n;
+}
+template <int W>
+__global__ __launch_bounds__(kT) void k_chunk_cams(int nchunks, const unsigned long long* csets, const int32_t* cam0, ChunkHdr* chunks, int32_t* chunk_cams) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c >= nchunks) return;
+  int at = cam0[c];
+  chunks[c].cam0 = at;
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    unsigned long long m = csets[(size_t)c * W + w];
+    while (m) { const int b = __builtin_ctzll(m); m &= m - 1; chunk_cams[at++] = w * 64 + b; }
+  }
 }
 
 __global__ __launch_bounds__(64) void k_seg_scan(int nseg, const int32_t* seg_nchunks, const int32_t* seg_ncams, int32_t* cbase, int32_t* cambase) {
@@ -335,12 +470,14 @@ struct RecOut {
 };
 __global__ __launch_bounds__(kT) void k_records(int n_order, int np_chunked, int n_withrec, int nrec_total, const int32_t* order, const LmInfo* info,
                                                 const int32_t* pstart, const int32_t* blk_cam, const int32_t* blk_key, const uint32_t* blk_src, const int32_t* rec_off,
-                                                const int32_t* fix_off, const int32_t* lm_chunk, const int32_t* cbase, int nseg, const ChunkHdr* chunks,
+                                                const int32_t* fix_off, int nchunks, const ChunkHdr* chunks,
                                                 const int32_t* chunk_cams, const uint8_t* pt_const, const double* obs_xy, const double* dobs_depth,
                                                 const double* dobs_mag, const double* dobs_par, const double* shift, RecOut O, unsigned long long* counters,
                                                 int32_t* err) {
   const int k = blockIdx.x * kT + threadIdx.x;
-  if (k >= n_order) return;
+  unsigned long long my_nblk = 0;
+  int my_var = 0;
+  if (k < n_order) {
   const int p = order[k];
   const LmInfo I = info[p];
   const int ps = pstart[p], n = pstart[p + 1] - ps;
@@ -351,10 +488,9 @@ __global__ __launch_bounds__(kT) void k_records(int n_order, int np_chunked, int
   ChunkHdr H{};
   const int32_t* cams = nullptr;
   if (chunked) {
-    int s = min((int)(((int64_t)k * nseg) / max(np_chunked, 1)), nseg - 1);  // the segment whose [k0, k1) holds k
-    while (s > 0 && (int64_t)np_chunked * s / nseg > k) --s;
-    while (s + 1 < nseg && (int64_t)np_chunked * (s + 1) / nseg <= k) ++s;
-    H = chunks[cbase[s] + lm_chunk[k]];
+    int lo = 0, hi = nchunks;  // the chunk whose landmarks [pt0, pt0 + npt) hold k
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunks[mid].pt0 <= k) lo = mid; else hi = mid; }
+    H = chunks[lo];
     cams = chunk_cams + H.cam0;
   }
   int f = fix_off[p];
@@ -387,8 +523,14 @@ __global__ __launch_bounds__(kT) void k_records(int n_order, int np_chunked, int
     ++w;
   });
   O.pt_kv[k] = (!cpt && k < n_withrec) ? (uint16_t)I.kv : (uint16_t)0xffff;
-  if (nblk) atomicAdd(&counters[0], nblk);
-  if (!cpt && k < n_withrec) atomicAdd(&counters[1], 1ull);
+  my_nblk = nblk; my_var = (!cpt && k < n_withrec) ? 1 : 0;
+  }
+  // totals: one atomic per wave
+  unsigned long long sb = my_nblk;
+  int sv = my_var;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sb += __shfl_xor(sb, off, 64); sv += __shfl_xor(sv, off, 64); }
+  if ((threadIdx.x & 63) == 0) { if (sb) atomicAdd(&counters[0], sb); if (sv) atomicAdd(&counters[1], (unsigned long long)sv); }
 }
 
 // rocPRIM calls with their temporary storage from the caching allocator
@@ -494,6 +636,15 @@ int DevBuilder::stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std:
 
 int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, DevBuildOut& out) {
   Impl& M = *m;
+  const bool tr = std::getenv("MPSFM_DEVBUILD_TRACE") != nullptr;  // diagnostics: synchronise and print after every step
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!tr) return;
+    (void)hipStreamSynchronize(M.s);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[mpsfm_ba] device build: %-34s %8.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   const size_t np = (size_t)M.np, nc = (size_t)M.nc;
   int rc = 0;
   int32_t* d_slot = M.alloc<int32_t>(nc);
@@ -506,6 +657,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   if ((rc = staged_drain())) return rc;
   const unsigned gnp = (unsigned)std::max<size_t>(1, (np + kT - 1) / kT);
   if (np) hipLaunchKernelGGL(k_sortmerge, dim3(gnp), dim3(kT), 0, M.s, M.np, M.pstart, M.blk_cam, M.blk_key, M.blk_src, d_slot, M.pt_const, dense_on ? 1 : 0, info, lm_slots);
+  lap("allocations + sort/merge per landmark");
   if (np) hipLaunchKernelGGL(k_flags, dim3(gnp), dim3(kT), 0, M.s, M.np, info, has_rec, fix_only, nfix);
   DB_TRY(hipMemsetAsync(has_rec + np, 0, 4, M.s));
   DB_TRY(hipMemsetAsync(fix_only + np, 0, 4, M.s));
@@ -518,29 +670,37 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   DB_TRY(hipMemcpyAsync(&tot[1], fpos + np, 4, hipMemcpyDeviceToHost, M.s));
   DB_TRY(hipMemcpyAsync(&tot[2], fix_off + np, 4, hipMemcpyDeviceToHost, M.s));
   DB_TRY(hipStreamSynchronize(M.s));
+  lap("flags + three scans + sync");
   const int n_withrec = tot[0], n_fixonly = tot[1], n_fixed = tot[2];
   const int n_order = n_withrec + n_fixonly;
   out.np = n_order; out.nfixed = n_fixed;
-  // ---- landmark order: (k1, k2, p) ascending by two stable radix sorts, then the stable class sort (normal | heavy | long)
+  // ---- landmark order (see k_candidates)
   const size_t nw = (size_t)std::max(n_withrec, 1);
-  unsigned long long *k2 = M.alloc<unsigned long long>(nw), *k2s = M.alloc<unsigned long long>(nw), *k1 = M.alloc<unsigned long long>(nw), *k1s = M.alloc<unsigned long long>(nw);
-  int32_t *idx = M.alloc<int32_t>(nw), *idx1 = M.alloc<int32_t>(nw), *cand = M.alloc<int32_t>(nw), *pg = M.alloc<int32_t>(nw), *order1 = M.alloc<int32_t>(nw);
-  uint32_t *cls = M.alloc<uint32_t>(nw), *cls_s = M.alloc<uint32_t>(nw);
+  unsigned long long *kA = M.alloc<unsigned long long>(nw), *kB = M.alloc<unsigned long long>(nw), *kS = M.alloc<unsigned long long>(nw), *kG = M.alloc<unsigned long long>(nw);
+  int32_t *cand = M.alloc<int32_t>(nw), *cand1 = M.alloc<int32_t>(nw);
   int32_t* order = M.alloc<int32_t>((size_t)std::max(n_order, 1));
   int32_t* counts = M.alloc<int32_t>(4);
-  if (!k2 || !k2s || !k1 || !k1s || !idx || !idx1 || !cand || !pg || !order1 || !cls || !cls_s || !order || !counts) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  if (!kA || !kB || !kS || !kG || !cand || !cand1 || !order || !counts) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
   DB_TRY(hipMemsetAsync(counts, 0, 16, M.s));
   int32_t cl[4] = {0, 0, 0, 0};
   if (n_withrec > 0) {
+    int nslots = 0;
+    for (int32_t v : slot_of_cam) nslots = std::max(nslots, v + 1);
+    int b = 1;
+    while ((1 << b) < nslots + 1) ++b;  // every slot below the all-ones value
+    const int single = 2 + 6 * b + 9 <= 64 ? 1 : 0;
     const unsigned gw = (unsigned)((n_withrec + kT - 1) / kT);
-    hipLaunchKernelGGL(k_candidates, dim3(gnp), dim3(kT), 0, M.s, M.np, info, pos, k2, idx, cand);
-    if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::radix_sort_pairs(t, b, k2, k2s, idx, idx1, (size_t)n_withrec, 0, 64, M.s); }))) return rc;
-    hipLaunchKernelGGL(k_gather_k1, dim3(gw), dim3(kT), 0, M.s, n_withrec, idx1, cand, info, k1, pg);
-    if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::radix_sort_pairs(t, b, k1, k1s, pg, order1, (size_t)n_withrec, 0, 64, M.s); }))) return rc;
-    hipLaunchKernelGGL(k_classes, dim3(gw), dim3(kT), 0, M.s, n_withrec, order1, info, cls, counts);
-    if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::radix_sort_pairs(t, b, cls, cls_s, order1, order, (size_t)n_withrec, 0, 2, M.s); }))) return rc;
+    hipLaunchKernelGGL(k_candidates, dim3(gnp), dim3(kT), 0, M.s, M.np, info, pos, b, single, kA, kB, cand, counts);
+    if (single) {
+      if ((rc = with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kA, kS, cand, order, (size_t)n_withrec, 0, (unsigned)(2 + 6 * b + 9), M.s); }))) return rc;
+    } else {
+      if ((rc = with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kB, kS, cand, cand1, (size_t)n_withrec, 0, (unsigned)(2 * b + 9), M.s); }))) return rc;
+      hipLaunchKernelGGL(k_gather_keys, dim3(gw), dim3(kT), 0, M.s, n_withrec, cand1, pos, kA, kG);
+      if ((rc = with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kG, kS, cand1, order, (size_t)n_withrec, 0, (unsigned)(2 + 4 * b), M.s); }))) return rc;
+    }
     DB_TRY(hipMemcpyAsync(cl, counts, 16, hipMemcpyDeviceToHost, M.s));
   }
+  lap("landmark order (radix sort)");
   if (n_fixonly > 0) hipLaunchKernelGGL(k_append_fixed_only, dim3(gnp), dim3(kT), 0, M.s, M.np, fix_only, fpos, n_withrec, order);
   int32_t* inv = M.alloc<int32_t>(np + 1);
   int32_t* nrec_k = M.alloc<int32_t>((size_t)n_order + 1);
@@ -552,31 +712,88 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   int32_t nrec_total = 0;
   DB_TRY(hipMemcpyAsync(&nrec_total, rec_off + n_order, 4, hipMemcpyDeviceToHost, M.s));
   DB_TRY(hipStreamSynchronize(M.s));
+  lap("inverse + record offsets + sync");
   const int n_long = cl[2];
   const int np_chunked = n_withrec - n_long;
   out.np_chunked = np_chunked; out.n_long = n_long; out.nrec = nrec_total;
   if (n_long > 0) return MPSFM_DEVBUILD_FALLBACK;  // long tracks: the host build handles them
   // ---- chunk cut
   const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(64, np_chunked / 4096));
-  TmpChunk* tmp_chunks = M.alloc<TmpChunk>((size_t)std::max(np_chunked, 1));
-  int32_t* tmp_cams = M.alloc<int32_t>((size_t)std::max(nrec_total, 1));
-  int32_t* lm_chunk = M.alloc<int32_t>((size_t)std::max(np_chunked, 1));
+  int nslots = 0;
+  for (int32_t v : slot_of_cam) nslots = std::max(nslots, v + 1);
+  const int W = std::max(1, (nslots + 63) / 64);
+  const bool jump = W <= 8;  // camera sets of up to 512 slots: the parallel form (k_next / k_walk); beyond: one wave per segment (k_cut)
   int32_t *seg_nch = M.alloc<int32_t>(65), *seg_ncam = M.alloc<int32_t>(65), *cbase = M.alloc<int32_t>(66), *cambase = M.alloc<int32_t>(66);
-  if (!tmp_chunks || !tmp_cams || !lm_chunk || !seg_nch || !seg_ncam || !cbase || !cambase) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  if (!seg_nch || !seg_ncam || !cbase || !cambase) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
   int32_t hb[2][66];
   std::memset(hb, 0, sizeof(hb));
-  if (np_chunked > 0) {
-    hipLaunchKernelGGL(k_cut, dim3(nseg), dim3(64), 0, M.s, np_chunked, nseg, order, info, lm_slots, M.pstart, M.blk_key, rec_off, tmp_chunks, tmp_cams, lm_chunk, seg_nch, seg_ncam);
+  TmpChunk* tmp_chunks = nullptr;
+  int32_t *tmp_cams = nullptr, *starts = nullptr;
+  unsigned long long* lmask = nullptr;
+  uint8_t* hvk = nullptr;
+  const int Wp = W <= 1 ? 1 : (W <= 2 ? 2 : (W <= 4 ? 4 : 8));  // the template instance
+  if (np_chunked > 0 && jump) {
+    lmask = M.alloc<unsigned long long>((size_t)np_chunked * Wp);
+    int32_t* rpk = M.alloc<int32_t>((size_t)np_chunked);
+    hvk = M.alloc<uint8_t>((size_t)np_chunked);
+    int32_t* next = M.alloc<int32_t>((size_t)np_chunked);
+    starts = M.alloc<int32_t>((size_t)np_chunked);
+    if (!lmask || !rpk || !hvk || !next || !starts) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+    const unsigned gk = (unsigned)((np_chunked + kT - 1) / kT);
+    DB_TRY(hipMemsetAsync(seg_ncam, 0, 4 * 65, M.s));
+    switch (Wp) {
+      case 1: hipLaunchKernelGGL(k_lm_masks<1>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
+              hipLaunchKernelGGL(k_next<1>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+      case 2: hipLaunchKernelGGL(k_lm_masks<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
+              hipLaunchKernelGGL(k_next<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+      case 4: hipLaunchKernelGGL(k_lm_masks<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
+              hipLaunchKernelGGL(k_next<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+      default: hipLaunchKernelGGL(k_lm_masks<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
+               hipLaunchKernelGGL(k_next<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+    }
+    hipLaunchKernelGGL(k_walk, dim3(1), dim3(64), 0, M.s, np_chunked, nseg, next, starts, seg_nch);
+    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(64), 0, M.s, nseg, seg_nch, seg_ncam, cbase, cambase);
+    DB_TRY(hipMemcpyAsync(hb[0], cbase, 4 * (size_t)(nseg + 1), hipMemcpyDeviceToHost, M.s));
+    DB_TRY(hipStreamSynchronize(M.s));
+  } else if (np_chunked > 0) {
+    tmp_chunks = M.alloc<TmpChunk>((size_t)np_chunked);
+    tmp_cams = M.alloc<int32_t>((size_t)std::max(nrec_total, 1));
+    int32_t* lm_chunk = M.alloc<int32_t>((size_t)np_chunked);
+    if (!tmp_chunks || !tmp_cams || !lm_chunk) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+    hipLaunchKernelGGL(k_cut, dim3(nseg), dim3(64), (size_t)64 * W * 8, M.s, np_chunked, nseg, W, order, info, lm_slots, M.pstart, M.blk_key, rec_off, tmp_chunks, tmp_cams, lm_chunk, seg_nch, seg_ncam);
     hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(64), 0, M.s, nseg, seg_nch, seg_ncam, cbase, cambase);
     DB_TRY(hipMemcpyAsync(hb[0], cbase, 4 * (size_t)(nseg + 1), hipMemcpyDeviceToHost, M.s));
     DB_TRY(hipMemcpyAsync(hb[1], cambase, 4 * (size_t)(nseg + 1), hipMemcpyDeviceToHost, M.s));
     DB_TRY(hipStreamSynchronize(M.s));
   }
-  const int nchunks = hb[0][nseg], ncams = hb[1][nseg];
+  lap("chunk cut");
+  const int nchunks = hb[0][nseg];
+  int ncams = hb[1][nseg];
   // ---- final tables (owned by the caller from here on)
   auto own = [&](size_t bytes) { return cached_malloc(std::max<size_t>(bytes, 8)); };
   const size_t nr = (size_t)std::max(nrec_total, 1), nf = (size_t)std::max(n_fixed, 1), no = (size_t)std::max(n_order, 1);
   out.d_chunks = (ChunkHdr*)own(sizeof(ChunkHdr) * (size_t)std::max(nchunks, 1));
+  if (!out.d_chunks) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  unsigned long long* csets = nullptr;
+  int32_t* cam0 = nullptr;
+  if (jump && nchunks > 0) {
+    // the chunks' camera sets and headers, the scan of their camera counts; the lists themselves once their table is sized
+    csets = M.alloc<unsigned long long>((size_t)nchunks * Wp);
+    int32_t* cncam = M.alloc<int32_t>((size_t)nchunks + 1);
+    cam0 = M.alloc<int32_t>((size_t)nchunks + 1);
+    if (!csets || !cncam || !cam0) { out.release(); return dfail(MPSFM_ENOMEM, "hipMalloc failed"); }
+    const unsigned gc = (unsigned)((nchunks + kT - 1) / kT);
+    switch (Wp) {
+      case 1: hipLaunchKernelGGL(k_chunk_sets<1>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
+      case 2: hipLaunchKernelGGL(k_chunk_sets<2>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
+      case 4: hipLaunchKernelGGL(k_chunk_sets<4>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
+      default: hipLaunchKernelGGL(k_chunk_sets<8>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
+    }
+    DB_TRY(hipMemsetAsync(cncam + nchunks, 0, 4, M.s));
+    if ((rc = with_temp([&](void* t, size_t& sz) { return rocprim::exclusive_scan(t, sz, cncam, cam0, 0, (size_t)nchunks + 1, rocprim::plus<int32_t>(), M.s); }))) { out.release(); return rc; }
+    DB_TRY(hipMemcpyAsync(&ncams, cam0 + nchunks, 4, hipMemcpyDeviceToHost, M.s));
+    DB_TRY(hipStreamSynchronize(M.s));
+  }
   out.d_chunk_cams = (int32_t*)own(4 * (size_t)std::max(ncams, 1));
   out.d_rec_cam = (int32_t*)own(4 * nr); out.d_rec_pt = (int32_t*)own(4 * nr); out.d_rec_meta = (uint32_t*)own(4 * nr);
   out.d_rec_xy = (double*)own(16 * nr); out.d_rec_d = (double*)own(8 * nr); out.d_rec_m = (double*)own(8 * nr); out.d_rec_a = (double*)own(8 * nr);
@@ -588,14 +805,23 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
                  out.d_pt_kv, out.d_fx_cam, out.d_fx_pt, out.d_fx_meta, out.d_fx_xy, out.d_fx_d, out.d_fx_m, out.d_fx_a, counters};
   for (void* p : all) if (!p) { out.release(); return dfail(MPSFM_ENOMEM, "hipMalloc failed"); }
   DB_TRY(hipMemsetAsync(counters, 0, 16, M.s));
-  if (nchunks > 0)
+  if (nchunks > 0 && jump) {
+    const unsigned gc = (unsigned)((nchunks + kT - 1) / kT);
+    switch (Wp) {
+      case 1: hipLaunchKernelGGL(k_chunk_cams<1>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
+      case 2: hipLaunchKernelGGL(k_chunk_cams<2>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
+      case 4: hipLaunchKernelGGL(k_chunk_cams<4>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
+      default: hipLaunchKernelGGL(k_chunk_cams<8>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
+    }
+  } else if (nchunks > 0)
     hipLaunchKernelGGL(k_chunks_final, dim3(nseg), dim3(kT), 0, M.s, np_chunked, nseg, tmp_chunks, tmp_cams, rec_off, order, info, cbase, cambase, out.d_chunks, out.d_chunk_cams);
   RecOut O{out.d_rec_cam, out.d_rec_pt, out.d_rec_meta, out.d_rec_xy, out.d_rec_d, out.d_rec_m, out.d_rec_a, out.d_pt_rec_start, out.d_pt_kv,
            out.d_fx_cam, out.d_fx_pt, out.d_fx_meta, out.d_fx_xy, out.d_fx_d, out.d_fx_m, out.d_fx_a};
   if (n_order > 0)
     hipLaunchKernelGGL(k_records, dim3((unsigned)((n_order + kT - 1) / kT)), dim3(kT), 0, M.s, n_order, np_chunked, n_withrec, nrec_total, order, info, M.pstart, M.blk_cam,
-                       M.blk_key, M.blk_src, rec_off, fix_off, lm_chunk, cbase, nseg, out.d_chunks, out.d_chunk_cams, M.pt_const, M.obs_xy, M.dobs_depth, M.dobs_mag,
+                       M.blk_key, M.blk_src, rec_off, fix_off, nchunks, out.d_chunks, out.d_chunk_cams, M.pt_const, M.obs_xy, M.dobs_depth, M.dobs_mag,
                        M.dobs_par, M.shift, O, counters, M.err);
+  lap("final tables: allocate, chunks, records");
   // the sentinel entry of pt_rec_start / pt_kv
   DB_TRY(hipMemcpyAsync(out.d_pt_rec_start + n_order, &nrec_total, 4, hipMemcpyHostToDevice, M.s));
   const uint16_t kv_none = 0xffff;
@@ -610,6 +836,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   DB_TRY(hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, M.s));
   DB_TRY(hipMemcpyAsync(er, M.err, 16, hipMemcpyDeviceToHost, M.s));
   DB_TRY(hipStreamSynchronize(M.s));
+  lap("downloads");
   if (er[0] & 2) { out.release(); return dfail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive"); }
   out.nblk_reduced = (int64_t)hc[0]; out.nvarpts = (double)hc[1];
   return 0;

@@ -61,7 +61,9 @@ def assert_same_tables(th, td):
             np.testing.assert_array_equal(a, b, err_msg=name)
 
 
-@pytest.mark.parametrize("ncam,npts,depth,seed", [(50, 20000, False, 0), (24, 9000, True, 3), (60, 30000, True, 4), (6, 300, True, 5)])
+@pytest.mark.parametrize("ncam,npts,depth,seed", [(50, 20000, False, 0), (24, 9000, True, 3), (60, 30000, True, 4), (6, 300, True, 5),
+                                                  (130, 12000, True, 6),    # camera sets of three 64-bit words
+                                                  (600, 9000, False, 7)])   # more than 512 slots: the wave-per-segment cut
 def test_device_build_equals_host_build(monkeypatch, ncam, npts, depth, seed):
     prob, _ = make_scene(ncam, npts, depth, seed=seed)
     th, td, sh, sd = both(prob, monkeypatch)
