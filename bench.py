@@ -48,7 +48,7 @@ def main():
     import torch
 
     from mpsfm_amd import capi
-    from mpsfm_amd.synthetic import CONFIGS, algorithmic_bytes_sweep, make_config
+    from mpsfm_amd.synthetic import CONFIGS, algorithmic_bytes_sweep, algorithmic_flops_sweep, make_config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,17 +131,34 @@ def main():
     # ---- roofline of the two priced kernels, timed live with HIP events on the solver's stream
     h.reset_state()
     reps = max(1, args.kernel_reps)
-    sweep_ms = float(np.mean([h.sweep_once(1e4) for _ in range(reps + 2)][2:]))
+    sweeps, parts = [], []
+    for _ in range(reps + 2):
+        sweeps.append(h.sweep_once(1e4))
+        parts.append(h.sweep_parts())
+    sweep_ms = float(np.mean(sweeps[2:]))
+    sweep_parts = {k: float(np.mean([p[k] for p in parts[2:]])) for k in ("dense_ms", "reduce_ms", "general_ms")}
+    sweep_parts.update({k: parts[-1][k] for k in ("dense_chunks", "general_chunks", "long_tracks", "reduce_parts")})
     dense_ms = float(np.mean([h.dense_solve_once() for _ in range(reps + 2)][2:]))
-    bytes_sweep = algorithmic_bytes_sweep(prob)
     n = h.reduced_dim
     plan = h.dense_plan()
+    bytes_sweep = algorithmic_bytes_sweep(prob, s_blocks=plan["s_blocks"])
+    flops_sweep = algorithmic_flops_sweep(prob)
     flops_dense = n**3 / 3.0 + 2.0 * n * n
     roof_sweep = {
-        "kernel": "k_track_sweep", "bound": "hbm", "achieved": bytes_sweep / (sweep_ms * 1e-3) / 1e9, "peak": 8000.0,
+        "kernel": "track sweep: k_track_sweep_dense + k_reduce_slabs (+ the general / long-track kernels where a problem has such chunks)",
+        "bound": "hbm", "achieved": bytes_sweep / (sweep_ms * 1e-3) / 1e9, "peak": 8000.0,
         "unit": "GB/s", "traffic": None, "algorithmic_bytes": bytes_sweep, "avg_ms": sweep_ms,
+        # HIP-event times of the three launches of one sweep (each carries ~5 us of event overhead; avg_ms spans all of them)
+        "launches": sweep_parts,
+        # the same launches against the fp64 vector peak (SURVEY 8d prices the sweep by bytes; by arithmetic intensity it sits on the
+        # compute side of the ridge): algorithmic flops, not issued ones
+        "fp64": {"algorithmic_flops": flops_sweep, "achieved_TFLOPs": flops_sweep / (sweep_ms * 1e-3) / 1e12, "peak_TFLOPs": 78.6,
+                 "frac": flops_sweep / (sweep_ms * 1e-3) / 1e12 / 78.6},
     }
     roof_sweep["frac"] = roof_sweep["achieved"] / roof_sweep["peak"]
+    # what the factorisation really issues on the matrix pipe: 32x32x32 tile products of the symbolic factor (2 * 32^3 each) plus
+    # the 32-column panel factorisations; the dense count above stands for the reduced system the caller handed over
+    issued_dense = 65536.0 * plan["tile_products"] + plan["tile_columns"] * (32.0**3 / 3.0 + 2.0 * 32.0**3)
     roof_dense = {
         "kernel": "k_chol_level (+k_assemble, back substitution): reduced camera system, level-scheduled tile Cholesky", "bound": "mfma", "achieved": flops_dense / (dense_ms * 1e-3) / 1e12,
         "peak": 78.6, "unit": "TFLOP/s", "traffic": None, "algorithmic_flops": flops_dense, "avg_ms": dense_ms, "n": n,
@@ -154,6 +171,8 @@ def main():
         # fill): the flops actually issued are fewer than the dense count `algorithmic_flops` (n^3/3 + 2 n^2)
         # that `achieved` is quoted on
         "note": "achieved = dense-equivalent flops / time; the factorisation skips structurally zero tiles",
+        "issued_flops_estimate": issued_dense, "issued_TFLOPs": issued_dense / (dense_ms * 1e-3) / 1e12,
+        "issued_frac": issued_dense / (dense_ms * 1e-3) / 1e12 / 78.6,
     }
     roof_dense["frac"] = roof_dense["achieved"] / roof_dense["peak"]
     t_lin, t_den, t_upd = last["time_linearize_s"], last["time_dense_s"], last["time_update_s"]
@@ -167,7 +186,7 @@ def main():
     if cands:
         try:
             tr = json.load(open(cands[-1]))
-            roof_sweep["traffic"] = tr.get("k_track_sweep_bytes_per_launch")
+            roof_sweep["traffic"] = tr.get("track_sweep_bytes_per_sweep", tr.get("k_track_sweep_bytes_per_launch"))
             roof_sweep["traffic_source"] = os.path.basename(cands[-1])
         except Exception:  # noqa: BLE001
             pass
@@ -230,6 +249,10 @@ def main():
             out["extras"]["one_shot_ms"] = one_shot_leg(local_rank)
         except Exception as e:  # noqa: BLE001
             out["extras"]["one_shot_ms"] = {"error": repr(e)}
+        try:  # what one Optimizer.ba() call pays from host buffers (device table build + uploads + solve + read-back): never `value`
+            out["one_shot_ms"] = {k: v.get("min") for k, v in out["extras"]["one_shot_ms"].items() if isinstance(v, dict)}
+        except Exception:  # noqa: BLE001
+            pass
         try:
             out["extras"]["other_configs_one_gpu"] = other_configs_leg(local_rank)
         except Exception as e:  # noqa: BLE001

@@ -226,12 +226,26 @@ def make_config(name: str, seed: int = 0, shard: int = 0) -> tuple[BAProblem, di
     return make_scene(n_cams, n_pts, with_depth=with_depth, seed=seed, shard=shard)
 
 
-def algorithmic_bytes_sweep(prob: BAProblem) -> int:
+def algorithmic_bytes_sweep(prob: BAProblem, s_blocks: int | None = None) -> int:
     """Compulsory HBM bytes of one track sweep: 24 B per reprojection block
     (2 indices + xy), 32 B per depth block (2 indices + d, m, a), 24 B per landmark (xyz read),
-    56 B per camera (pose read) and 8 B per entry of the reduced camera system written once."""
+    56 B per camera (pose read) and the reduced camera system written once: its `s_blocks` 6x6 blocks
+    (the block-sparse buffer the solver keeps) plus the three slot vectors; without
+    `s_blocks` the dense 8 n^2 of SURVEY.md §8d."""
     n = 6 * prob.n_cams
-    return 24 * prob.n_obs + 32 * prob.n_dobs + 24 * prob.n_pts + 56 * prob.n_cams + 8 * n * n
+    s_bytes = 8 * n * n if s_blocks is None else 8 * 36 * int(s_blocks) + 3 * 8 * n
+    return 24 * prob.n_obs + 32 * prob.n_dobs + 24 * prob.n_pts + 56 * prob.n_cams + s_bytes
+
+
+def algorithmic_flops_sweep(prob: BAProblem) -> int:
+    """fp64 operations one track sweep has to do (multiply-add = 2): per reprojection block the 2-row functor with its
+    Jacobian (~120) and its share of J^T J (U 21, V 6, W 18, g_c 6, g_p 3 entries x 2 rows x 2), per depth block the
+    1-row versions, per (camera, landmark) record Z = W F^T and W V^-1 g_p (54 + 36), per landmark the 3x3 factorisation
+    (~50) and the Schur products of its camera pairs (upper triangle incl. the diagonal, 6x3 * 3x6 = 216 each)."""
+    k = np.bincount(np.unique(np.stack([prob.obs_pt, prob.obs_cam], 1), axis=0)[:, 0], minlength=prob.n_pts).astype(np.int64)
+    pairs = int(np.sum(k * (k + 1) // 2))
+    per_row = 2 * (21 + 6 + 18 + 6 + 3)
+    return int(prob.n_obs * (120 + 2 * per_row) + prob.n_dobs * (60 + per_row) + int(k.sum()) * 90 + prob.n_pts * 50 + pairs * 216)
 
 
 def local_window(prob: BAProblem, window_cams, ref_cam: int, max_track: int = 15):
