@@ -533,17 +533,6 @@ __global__ __launch_bounds__(kT) void k_records(int n_order, int np_chunked, int
   if ((threadIdx.x & 63) == 0) { if (sb) atomicAdd(&counters[0], sb); if (sv) atomicAdd(&counters[1], (unsigned long long)sv); }
 }
 
-// rocPRIM calls with their temporary storage from the caching allocator
-template <class F>
-int with_temp(F&& f) {
-  size_t bytes = 0;
-  if (f(nullptr, bytes) != hipSuccess) return dfail(MPSFM_EHIP, "rocPRIM size query failed");
-  void* tmp = cached_malloc(std::max<size_t>(bytes, 16));
-  if (!tmp) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
-  const hipError_t e = f(tmp, bytes);
-  cached_free(tmp);  // stream-ordered use: the block goes back to the cache, handed out again only to later work of this thread's streams
-  return e == hipSuccess ? 0 : dfail(MPSFM_EHIP, "rocPRIM call failed");
-}
 }  // namespace
 
 struct DevBuilder::Impl {
@@ -552,6 +541,17 @@ struct DevBuilder::Impl {
   int64_t n_obs = 0, n_dobs = 0, nblk = 0;
   std::vector<void*> blocks;  // everything to give back
   template <class T> T* alloc(size_t n) { T* p = (T*)cached_malloc(std::max<size_t>(n, 1) * sizeof(T)); if (p) blocks.push_back(p); return p; }
+  // rocPRIM calls with their temporary storage.  The block stays with the builder until its destructor has synchronised the
+  // stream: the caching allocator is process-wide, a block given back while the call is still queued could be handed to another
+  // host thread's handle at once and written from ITS stream (the hazard of DESIGN.md section 4b).
+  template <class F>
+  int with_temp(F&& f) {
+    size_t bytes = 0;
+    if (f(nullptr, bytes) != hipSuccess) return dfail(MPSFM_EHIP, "rocPRIM size query failed");
+    void* tmp = alloc<uint8_t>(std::max<size_t>(bytes, 16));
+    if (!tmp) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+    return f(tmp, bytes) == hipSuccess ? 0 : dfail(MPSFM_EHIP, "rocPRIM call failed");
+  }
   // raw input
   int32_t *obs_cam = nullptr, *obs_pt = nullptr, *dobs_cam = nullptr, *dobs_pt = nullptr;
   double *obs_xy = nullptr, *dobs_depth = nullptr, *dobs_mag = nullptr, *dobs_par = nullptr, *shift = nullptr;
@@ -610,7 +610,7 @@ int DevBuilder::stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std:
   const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (M.nblk + kT - 1) / kT));
   hipLaunchKernelGGL(k_count, dim3(grid), dim3(kT), (size_t)4 * std::max(M.nc, 1), M.s, M.n_obs, M.n_dobs, M.obs_cam, M.obs_pt, M.dobs_cam, M.dobs_pt, M.dobs_depth,
                      M.nc, M.np, M.cnt_pt, M.cnt_cam, M.err);
-  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, M.cnt_pt, M.pstart, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, M.cnt_pt, M.pstart, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
   hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(kT), 0, M.s, M.n_obs, M.n_dobs, M.obs_cam, M.obs_pt, M.dobs_cam, M.dobs_pt, M.pstart, M.fill, M.blk_cam, M.blk_src);
   if (ncv_real > 0 && np)
     hipLaunchKernelGGL(k_graph, dim3((unsigned)((np + kT - 1) / kT)), dim3(kT), 0, M.s, M.np, M.pstart, M.blk_cam, M.pt_const, M.nat, graph_words, M.bits);
@@ -623,7 +623,7 @@ int DevBuilder::stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std:
   // the longest block list: a max-reduction over the counts (rocPRIM)
   int32_t* d_max = M.alloc<int32_t>(1);
   if (!d_max) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
-  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::reduce(t, b, M.cnt_pt, d_max, 0, np + 1, rocprim::maximum<int32_t>(), M.s); }))) return rc;
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::reduce(t, b, M.cnt_pt, d_max, 0, np + 1, rocprim::maximum<int32_t>(), M.s); }))) return rc;
   int32_t mx = 0;
   DB_TRY(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, M.s));
   DB_TRY(hipStreamSynchronize(M.s));
@@ -662,9 +662,9 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   DB_TRY(hipMemsetAsync(has_rec + np, 0, 4, M.s));
   DB_TRY(hipMemsetAsync(fix_only + np, 0, 4, M.s));
   DB_TRY(hipMemsetAsync(nfix + np, 0, 4, M.s));
-  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, has_rec, pos, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
-  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, fix_only, fpos, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
-  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, nfix, fix_off, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, has_rec, pos, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, fix_only, fpos, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, nfix, fix_off, 0, np + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
   int32_t tot[3] = {0, 0, 0};
   DB_TRY(hipMemcpyAsync(&tot[0], pos + np, 4, hipMemcpyDeviceToHost, M.s));
   DB_TRY(hipMemcpyAsync(&tot[1], fpos + np, 4, hipMemcpyDeviceToHost, M.s));
@@ -692,11 +692,11 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
     const unsigned gw = (unsigned)((n_withrec + kT - 1) / kT);
     hipLaunchKernelGGL(k_candidates, dim3(gnp), dim3(kT), 0, M.s, M.np, info, pos, b, single, kA, kB, cand, counts);
     if (single) {
-      if ((rc = with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kA, kS, cand, order, (size_t)n_withrec, 0, (unsigned)(2 + 6 * b + 9), M.s); }))) return rc;
+      if ((rc = M.with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kA, kS, cand, order, (size_t)n_withrec, 0, (unsigned)(2 + 6 * b + 9), M.s); }))) return rc;
     } else {
-      if ((rc = with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kB, kS, cand, cand1, (size_t)n_withrec, 0, (unsigned)(2 * b + 9), M.s); }))) return rc;
+      if ((rc = M.with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kB, kS, cand, cand1, (size_t)n_withrec, 0, (unsigned)(2 * b + 9), M.s); }))) return rc;
       hipLaunchKernelGGL(k_gather_keys, dim3(gw), dim3(kT), 0, M.s, n_withrec, cand1, pos, kA, kG);
-      if ((rc = with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kG, kS, cand1, order, (size_t)n_withrec, 0, (unsigned)(2 + 4 * b), M.s); }))) return rc;
+      if ((rc = M.with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, kG, kS, cand1, order, (size_t)n_withrec, 0, (unsigned)(2 + 4 * b), M.s); }))) return rc;
     }
     DB_TRY(hipMemcpyAsync(cl, counts, 16, hipMemcpyDeviceToHost, M.s));
   }
@@ -708,7 +708,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   if (!inv || !nrec_k || !rec_off) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
   if (n_order > 0) hipLaunchKernelGGL(k_inverse, dim3((unsigned)((n_order + kT - 1) / kT)), dim3(kT), 0, M.s, n_order, order, info, inv, nrec_k, n_withrec);
   DB_TRY(hipMemsetAsync(nrec_k + n_order, 0, 4, M.s));
-  if ((rc = with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, nrec_k, rec_off, 0, (size_t)n_order + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, nrec_k, rec_off, 0, (size_t)n_order + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
   int32_t nrec_total = 0;
   DB_TRY(hipMemcpyAsync(&nrec_total, rec_off + n_order, 4, hipMemcpyDeviceToHost, M.s));
   DB_TRY(hipStreamSynchronize(M.s));
@@ -781,7 +781,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
     csets = M.alloc<unsigned long long>((size_t)nchunks * Wp);
     int32_t* cncam = M.alloc<int32_t>((size_t)nchunks + 1);
     cam0 = M.alloc<int32_t>((size_t)nchunks + 1);
-    if (!csets || !cncam || !cam0) { out.release(); return dfail(MPSFM_ENOMEM, "hipMalloc failed"); }
+    if (!csets || !cncam || !cam0) { (void)hipStreamSynchronize(M.s); out.release(); return dfail(MPSFM_ENOMEM, "hipMalloc failed"); }
     const unsigned gc = (unsigned)((nchunks + kT - 1) / kT);
     switch (Wp) {
       case 1: hipLaunchKernelGGL(k_chunk_sets<1>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
@@ -790,7 +790,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
       default: hipLaunchKernelGGL(k_chunk_sets<8>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
     }
     DB_TRY(hipMemsetAsync(cncam + nchunks, 0, 4, M.s));
-    if ((rc = with_temp([&](void* t, size_t& sz) { return rocprim::exclusive_scan(t, sz, cncam, cam0, 0, (size_t)nchunks + 1, rocprim::plus<int32_t>(), M.s); }))) { out.release(); return rc; }
+    if ((rc = M.with_temp([&](void* t, size_t& sz) { return rocprim::exclusive_scan(t, sz, cncam, cam0, 0, (size_t)nchunks + 1, rocprim::plus<int32_t>(), M.s); }))) { (void)hipStreamSynchronize(M.s); out.release(); return rc; }
     DB_TRY(hipMemcpyAsync(&ncams, cam0 + nchunks, 4, hipMemcpyDeviceToHost, M.s));
     DB_TRY(hipStreamSynchronize(M.s));
   }
@@ -803,7 +803,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   unsigned long long* counters = M.alloc<unsigned long long>(2);
   void* all[] = {out.d_chunks, out.d_chunk_cams, out.d_rec_cam, out.d_rec_pt, out.d_rec_meta, out.d_rec_xy, out.d_rec_d, out.d_rec_m, out.d_rec_a, out.d_pt_rec_start,
                  out.d_pt_kv, out.d_fx_cam, out.d_fx_pt, out.d_fx_meta, out.d_fx_xy, out.d_fx_d, out.d_fx_m, out.d_fx_a, counters};
-  for (void* p : all) if (!p) { out.release(); return dfail(MPSFM_ENOMEM, "hipMalloc failed"); }
+  for (void* p : all) if (!p) { (void)hipStreamSynchronize(M.s); out.release(); return dfail(MPSFM_ENOMEM, "hipMalloc failed"); }
   DB_TRY(hipMemsetAsync(counters, 0, 16, M.s));
   if (nchunks > 0 && jump) {
     const unsigned gc = (unsigned)((nchunks + kT - 1) / kT);
