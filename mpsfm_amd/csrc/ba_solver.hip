@@ -451,7 +451,7 @@ struct mpsfm_ba_handle {
   RedDest* d_red_dests = nullptr;   // slab reduction: destination parts and their sources
   int32_t* d_red_srcs = nullptr;
   int n_red_dests = 0;
-  int64_t n_red_srcs = 0, n_chunk_cams = 0;  // table sizes (diagnostics: mpsfm_debug_table)
+  int64_t n_red_srcs = 0, n_chunk_cams = 0, n_blk_desc = 0, n_blk_ent_start = 0, n_ents = 0;  // table sizes (diagnostics: mpsfm_debug_table)
   bool built_on_device = false;
   LongHdr* d_lhdr = nullptr;
   double* d_wl = nullptr;
@@ -773,6 +773,79 @@ static int upload_plan(mpsfm_ba_handle* h, int64_t nblk) {
   return 0;
 }
 
+// Pair tables of ONE chunk for the general kernel, appended to (blk_desc, ents, blk_ent_start): the Schur pairs of its variable
+// landmarks grouped by the 6x6 destination block (counting sort, heaviest blocks first), cut into work items of at most kItemPairs
+// pairs; a dense chunk only gets its sentinel.  `rec_meta` is indexed by the global record, `pt_kv` / `pt_rec_start` / `order` by the
+// re-ordered landmark.  Shared by the host build and by the device build's general chunks.
+struct PairEnt { uint16_t key; uint32_t ent; };
+struct PairScratch {
+  std::vector<PairEnt> pe, pe_sorted;
+  std::vector<std::pair<int, int>> blk_order, items;  // (count, first index into pe)
+  std::vector<int32_t> cnt;
+};
+static void append_pair_tables(ChunkHdr& H, const uint32_t* rec_meta, const uint16_t* pt_kv, const int32_t* pt_rec_start, const int32_t* order,
+                               const uint8_t* pt_const, std::vector<uint32_t>& o_blk_desc, std::vector<uint32_t>& o_ents, std::vector<int32_t>& o_blk_ent_start,
+                               PairScratch& S) {
+  std::vector<PairEnt>&pe = S.pe, &pe_sorted = S.pe_sorted;
+  std::vector<std::pair<int, int>>&blk_order = S.blk_order, &items = S.items;
+  std::vector<int32_t>& cnt = S.cnt;
+  const int64_t c_first = H.pt0, end_pt = (int64_t)H.pt0 + H.npt;
+  pe.clear();
+  if (!H.dense) {
+    for (int64_t k = c_first; k < end_pt; ++k) {
+      const int p = order[k];
+      if (pt_const[p]) continue;
+      // Schur pairs of this landmark: records rbase .. rbase+kv-1 have variable cameras (slot-sorted)
+      const int rbase = pt_rec_start[(size_t)k] - H.rec0;
+      const int kv = (int)pt_kv[(size_t)k];
+      const uint32_t lpt = (uint32_t)(k - c_first);
+      for (int i = 0; i < kv; ++i) {
+        const uint32_t li = rec_meta[(size_t)H.rec0 + rbase + i] & 0xff;
+        for (int j = i; j < kv; ++j) {
+          const uint32_t lj = rec_meta[(size_t)H.rec0 + rbase + j] & 0xff;
+          pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + i) | ((uint32_t)(rbase + j) << 8) | (lpt << 16)});
+          // two records of one camera: the diagonal block needs B + B^T
+          if (li == lj && i != j)
+            pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + j) | ((uint32_t)(rbase + i) << 8) | (lpt << 16)});
+        }
+      }
+    }
+  }
+  // group the pairs by destination block (counting sort on li*ncam+lj); heaviest blocks first
+  {
+    const int nl = std::max(H.ncam, 1);
+    cnt.assign((size_t)nl * nl + 1, 0);
+    for (const PairEnt& e : pe) cnt[(size_t)(e.key & 0xff) * nl + (e.key >> 8) + 1]++;
+    for (size_t q = 1; q < cnt.size(); ++q) cnt[q] += cnt[q - 1];
+    pe_sorted.resize(pe.size());
+    for (const PairEnt& e : pe) pe_sorted[(size_t)cnt[(size_t)(e.key & 0xff) * nl + (e.key >> 8)]++] = e;
+    pe.swap(pe_sorted);
+  }
+  blk_order.clear();
+  for (size_t i = 0; i < pe.size();) {
+    size_t j = i;
+    while (j < pe.size() && pe[j].key == pe[i].key) ++j;
+    blk_order.emplace_back((int)(j - i), (int)i);
+    i = j;
+  }
+  std::stable_sort(blk_order.begin(), blk_order.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+  // work items: runs of at most kItemPairs pairs of one block.  Block-major: all items of a block are
+  // neighbours, so the flush combines them (one atomic pass per block and round)
+  items.clear();
+  for (const auto& bo : blk_order)
+    for (int q = 0; q < bo.first; q += kItemPairs) items.emplace_back(std::min(kItemPairs, bo.first - q), bo.second + q);
+  H.blk0 = (int32_t)o_blk_desc.size();  // thread-local for now
+  H.ent0 = (int32_t)o_ents.size();
+  H.nent = (int32_t)pe.size();
+  H.nblk = (int32_t)items.size();
+  for (const auto& it : items) {
+    o_blk_desc.push_back(pe[(size_t)it.second].key);
+    o_blk_ent_start.push_back((int32_t)(o_ents.size() - (size_t)H.ent0));
+    for (int q = 0; q < it.first; ++q) o_ents.push_back(pe[(size_t)(it.second + q)].ent);
+  }
+  o_blk_ent_start.push_back((int32_t)(o_ents.size() - (size_t)H.ent0));  // per-chunk sentinel
+}
+
 static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_state* st) {
   const int nc = P->n_cams, npu = P->n_pts;
   auto t_prev = std::chrono::steady_clock::now();
@@ -971,11 +1044,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     const bool dense_on = !(std::getenv("MPSFM_SWEEP_DENSE") && std::atoi(std::getenv("MPSFM_SWEEP_DENSE")) == 0);
     const int rc2 = devb->stage2(slot, dense_on, DB);
     if (rc2 < 0) return rc2;
-    bool general = false;
-    if (rc2 == 0) for (const ChunkHdr& H : DB.chunks) general = general || !H.dense;
-    if (rc2 == MPSFM_DEVBUILD_FALLBACK || general) {
-      // long tracks, or chunks for the general kernel (their pair tables are host work): the host phases run after all — Phase A
-      // first, which was skipped
+    if (rc2 == MPSFM_DEVBUILD_FALLBACK) {
+      // long tracks: the host phases run after all — Phase A first, which was skipped
       DB.release();
       dev = false;
       run_parts(mparts, [&](int t, int nparts) {
@@ -1011,8 +1081,29 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       h->nchunks = (int)chunks.size();
       h->nlong = 0; h->nrec = nrec_total; h->nblocks_reduced = nblk_reduced;
       h->nblocks_global = (double)h->nblocks_total; h->nblocks_reduced_global = (double)nblk_reduced; h->nvarpts_global = nvarpts;
-      blk_ent_start.assign(chunks.size(), 0);  // the per-chunk sentinels of the (empty) pair tables
       lap("device stage 2 (order, chunks, records)");
+      // pair tables: a sentinel per dense chunk; the general chunks (landmarks with more than kDenseCams cameras or two records of one
+      // camera; they come last) get theirs from the host, which needs their record words and landmark tables back
+      size_t g0 = 0;
+      while (g0 < chunks.size() && chunks[g0].dense) ++g0;
+      blk_ent_start.assign(g0, 0);
+      if (g0 < chunks.size()) {
+        const int64_t r0 = chunks[g0].rec0, k0 = chunks[g0].pt0, nrg = nrec_total - r0, nkg = h->np_chunked - k0;
+        std::vector<uint32_t> rm((size_t)std::max<int64_t>(nrg, 1));
+        std::vector<uint16_t> kvs((size_t)std::max<int64_t>(nkg, 1));
+        std::vector<int32_t> prs((size_t)std::max<int64_t>(nkg, 1));
+        HIP_TRY(hipMemcpyAsync(rm.data(), DB.d_rec_meta + r0, 4 * (size_t)nrg, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(kvs.data(), DB.d_pt_kv + k0, 2 * (size_t)nkg, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(prs.data(), DB.d_pt_rec_start + k0, 4 * (size_t)nkg, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        PairScratch ps;
+        for (size_t c = g0; c < chunks.size(); ++c) {
+          if (chunks[c].dense) return fail(MPSFM_EUNSUPPORTED, "internal: dense chunks must precede the general ones");
+          append_pair_tables(chunks[c], rm.data() - r0, kvs.data() - k0, prs.data() - k0, h->perm.data(), P->pt_const, blk_desc, ents, blk_ent_start, ps);
+        }
+        if (ents.size() > (size_t)INT32_MAX) return fail(MPSFM_EUNSUPPORTED, "too many Schur pairs for 32-bit entry offsets");
+        lap("pair tables of the general chunks (host)");
+      }
     }
   }
   if (!dev) {
@@ -1253,7 +1344,6 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     const size_t nr = (size_t)nrec_total;
     rec_cam.alloc(nr); rec_pt.alloc(nr); rec_meta.alloc(nr); rec_xy.alloc(2 * nr); rec_d.alloc(nr); rec_m.alloc(nr); rec_a.alloc(nr);
     lap("size record arrays");
-    struct PairEnt { uint16_t key; uint32_t ent; };
     struct ChunkPart {
       std::vector<uint32_t> blk_desc, ents;
       std::vector<int32_t> blk_ent_start;
@@ -1265,14 +1355,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     std::vector<ChunkPart> cp((size_t)cparts);
     run_parts(cparts, [&](int t, int nparts) {
       ChunkPart& C = cp[(size_t)t];
-      std::vector<PairEnt> pe, pe_sorted;
-      std::vector<std::pair<int, int>> blk_order, items;  // (count, first index into pe)
-      std::vector<int32_t> cnt;
+      PairScratch ps;
       for (int c = (int)((int64_t)nch * t / nparts); c < (int)((int64_t)nch * (t + 1) / nparts); ++c) {
         ChunkHdr& H = chunks[(size_t)c];
         const int32_t* cams = chunk_cams.data() + H.cam0;
         const int64_t c_first = H.pt0, end_pt = (int64_t)H.pt0 + H.npt;
-        pe.clear();
         bool dup = false;    // two records of one camera for one variable landmark
         int64_t w = H.rec0;  // next record
         for (int64_t k = c_first; k < end_pt; ++k) {
@@ -1304,59 +1391,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
         H.dense = heavy_flag[(size_t)order[(size_t)c_first]] ? 0 : 1;  // by construction: <= kDenseCams cameras, <= kDensePts landmarks, no duplicates
         H.slab0 = 0;
         (void)dup;
-        if (!H.dense) {
-          for (int64_t k = c_first; k < end_pt; ++k) {
-            const int p = order[k];
-            if (P->pt_const[p]) continue;
-            // Schur pairs of this landmark: records rbase .. rbase+kv-1 have variable cameras (slot-sorted)
-            const int rbase = pt_rec_start[(size_t)k] - H.rec0;
-            const int kv = (int)pt_kv[(size_t)k];
-            const uint32_t lpt = (uint32_t)(k - c_first);
-            for (int i = 0; i < kv; ++i) {
-              const uint32_t li = rec_meta[(size_t)H.rec0 + rbase + i] & 0xff;
-              for (int j = i; j < kv; ++j) {
-                const uint32_t lj = rec_meta[(size_t)H.rec0 + rbase + j] & 0xff;
-                pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + i) | ((uint32_t)(rbase + j) << 8) | (lpt << 16)});
-                // two records of one camera: the diagonal block needs B + B^T
-                if (li == lj && i != j)
-                  pe.push_back(PairEnt{(uint16_t)(li | (lj << 8)), (uint32_t)(rbase + j) | ((uint32_t)(rbase + i) << 8) | (lpt << 16)});
-              }
-            }
-          }
-        }
-        // group the pairs by destination block (counting sort on li*ncam+lj); heaviest blocks first
-        {
-          const int nl = std::max(H.ncam, 1);
-          cnt.assign((size_t)nl * nl + 1, 0);
-          for (const PairEnt& e : pe) cnt[(size_t)(e.key & 0xff) * nl + (e.key >> 8) + 1]++;
-          for (size_t q = 1; q < cnt.size(); ++q) cnt[q] += cnt[q - 1];
-          pe_sorted.resize(pe.size());
-          for (const PairEnt& e : pe) pe_sorted[(size_t)cnt[(size_t)(e.key & 0xff) * nl + (e.key >> 8)]++] = e;
-          pe.swap(pe_sorted);
-        }
-        blk_order.clear();
-        for (size_t i = 0; i < pe.size();) {
-          size_t j = i;
-          while (j < pe.size() && pe[j].key == pe[i].key) ++j;
-          blk_order.emplace_back((int)(j - i), (int)i);
-          i = j;
-        }
-        std::stable_sort(blk_order.begin(), blk_order.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
-        // work items: runs of at most kItemPairs pairs of one block.  Block-major: all items of a block are
-        // neighbours, so the flush combines them (one atomic pass per block and round)
-        items.clear();
-        for (const auto& bo : blk_order)
-          for (int q = 0; q < bo.first; q += kItemPairs) items.emplace_back(std::min(kItemPairs, bo.first - q), bo.second + q);
-        H.blk0 = (int32_t)C.blk_desc.size();  // thread-local for now
-        H.ent0 = (int32_t)C.ents.size();
-        H.nent = (int32_t)pe.size();
-        H.nblk = (int32_t)items.size();
-        for (const auto& it : items) {
-          C.blk_desc.push_back(pe[(size_t)it.second].key);
-          C.blk_ent_start.push_back((int32_t)(C.ents.size() - (size_t)H.ent0));
-          for (int q = 0; q < it.first; ++q) C.ents.push_back(pe[(size_t)(it.second + q)].ent);
-        }
-        C.blk_ent_start.push_back((int32_t)(C.ents.size() - (size_t)H.ent0));  // per-chunk sentinel
+        append_pair_tables(H, rec_meta.data(), pt_kv.data(), pt_rec_start.data(), order.data(), P->pt_const, C.blk_desc, C.ents, C.blk_ent_start, ps);
       }
     });
     lap("chunk records + pairs (threads)");
@@ -1633,6 +1668,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   }
   if ((rc = dev_upload(&h->d_lhdr, lhdr))) return rc;
   if ((rc = dev_alloc(&h->d_wl, (size_t)std::max<int64_t>(wl_rows, 1) * 18))) return rc;
+  h->n_blk_desc = (int64_t)blk_desc.size(); h->n_blk_ent_start = (int64_t)blk_ent_start.size(); h->n_ents = (int64_t)ents.size();
   if ((rc = dev_upload(&h->d_blk_desc, blk_desc))) return rc;
   if ((rc = dev_upload(&h->d_blk_ent_start, blk_ent_start))) return rc;
   if ((rc = dev_upload(&h->d_ents, ents))) return rc;
@@ -2272,7 +2308,8 @@ int mpsfm_debug_read_trace(mpsfm_ba_handle* h, long long* out, int64_t count) {
 // Diagnostics / tests (tests/test_gpu_devbuild.py): table `which` of the handle copied to `out` (at most `cap` bytes); returns the
 // table's size in bytes, or a negative error code.  which: 0 chunk headers, 1 chunk cameras, 2 rec_cam, 3 rec_pt, 4 rec_meta, 5 rec_xy,
 // 6 rec_d, 7 rec_m, 8 rec_a, 9 pt_rec_start, 10 pt_kv, 11 fx_cam, 12 fx_pt, 13 fx_meta, 14 fx_xy, 15 fx_d, 16 fx_m, 17 fx_a,
-// 18 landmark order (host), 19 reduction destinations, 20 reduction sources, 21 camera slots (host), 22: 1 byte, built on the device?
+// 18 landmark order (host), 19 reduction destinations, 20 reduction sources, 21 camera slots (host), 22: 1 byte, built on the device?,
+// 23 blk_desc, 24 blk_ent_start, 25 ents (pair tables of the general chunks)
 int64_t mpsfm_debug_table(mpsfm_ba_handle* h, int32_t which, void* out, int64_t cap) {
   if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
   const void* src = nullptr;
@@ -2302,6 +2339,9 @@ int64_t mpsfm_debug_table(mpsfm_ba_handle* h, int32_t which, void* out, int64_t 
     case 19: src = h->d_red_dests; bytes = (int64_t)sizeof(RedDest) * h->n_red_dests; break;
     case 20: src = h->d_red_srcs; bytes = 4 * h->n_red_srcs; break;
     case 21: src = h->cam_slot_h.data(); bytes = 4 * (int64_t)h->cam_slot_h.size(); host = true; break;
+    case 23: src = h->d_blk_desc; bytes = 4 * h->n_blk_desc; break;
+    case 24: src = h->d_blk_ent_start; bytes = 4 * h->n_blk_ent_start; break;
+    case 25: src = h->d_ents; bytes = 4 * h->n_ents; break;
     case 22: { static uint8_t flag; flag = h->built_on_device ? 1 : 0; src = &flag; bytes = 1; host = true; break; }
     default: return fail(MPSFM_EINVAL, "unknown table");
   }

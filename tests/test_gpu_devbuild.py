@@ -17,7 +17,8 @@ TABLES = {0: ("chunks", np.int32), 1: ("chunk_cams", np.int32), 2: ("rec_cam", n
           5: ("rec_xy", np.float64), 6: ("rec_d", np.float64), 7: ("rec_m", np.float64), 8: ("rec_a", np.float64), 9: ("pt_rec_start", np.int32),
           10: ("pt_kv", np.uint16), 11: ("fx_cam", np.int32), 12: ("fx_pt", np.int32), 13: ("fx_meta", np.uint32), 14: ("fx_xy", np.float64),
           15: ("fx_d", np.float64), 16: ("fx_m", np.float64), 17: ("fx_a", np.float64), 18: ("order", np.int32), 19: ("red_dests", np.int32),
-          20: ("red_srcs", np.int32), 21: ("cam_slot", np.int32), 22: ("built_on_device", np.uint8)}
+          20: ("red_srcs", np.int32), 21: ("cam_slot", np.int32), 22: ("built_on_device", np.uint8), 23: ("blk_desc", np.uint32),
+          24: ("blk_ent_start", np.int32), 25: ("ents", np.uint32)}
 
 
 def tables(h):
@@ -86,9 +87,30 @@ def test_device_build_with_constant_cameras_points_and_fixed_blocks(monkeypatch)
     assert sd["final_cost"] == pytest.approx(sh["final_cost"], rel=1e-10) and sh["num_iterations"] == sd["num_iterations"]
 
 
-def test_problems_the_device_build_hands_back(monkeypatch):
-    """Long tracks and landmarks with more than 16 cameras (general chunks) take the host phases; the handle says so and solves."""
-    prob, _ = make_scene(40, 3000, True, seed=2, max_track=40, track_mean=25.0)
+def test_general_chunks_get_their_pair_tables_from_the_host(monkeypatch):
+    """Landmarks with more than 16 cameras (and landmarks with two records of one camera) form general chunks behind the dense ones:
+    the device build keeps everything else and asks the host for their pair tables only — all tables equal the host build's."""
+    prob, _ = make_scene(40, 3000, True, seed=2, max_track=40, track_mean=12.0)
+    dup = np.flatnonzero(prob.obs_pt == 5)[:1]   # a second reprojection block of one camera on landmark 5
+    prob.obs_cam = np.concatenate([prob.obs_cam, prob.obs_cam[dup]]); prob.obs_pt = np.concatenate([prob.obs_pt, prob.obs_pt[dup]])
+    prob.obs_xy = np.concatenate([prob.obs_xy, prob.obs_xy[dup] + 0.5])
+    th, td, sh, sd = both(prob, monkeypatch)
+    assert_same_tables(th, td)
+    dense = th["chunks"].reshape(-1, 12)[:, 10]
+    assert (dense == 0).any() and (dense == 1).any() and len(th["ents"]) > 0
+    assert sd["final_cost"] == pytest.approx(sh["final_cost"], rel=1e-10) and sh["num_iterations"] == sd["num_iterations"]
+
+
+def test_long_tracks_take_the_host_build():
+    """A landmark with more blocks than a chunk holds (here: seen by 300 cameras) is swept by a workgroup of its own; such problems
+    keep the host phases, the handle says so and solves."""
+    prob, truth = make_scene(300, 2000, False, seed=4)
+    from mpsfm_amd.synthetic import R_from_quat
+    R = R_from_quat(truth["cam_quat"])
+    Xc = R @ truth["pts"][0] + truth["cam_t"]
+    uv = np.stack([1200 * Xc[:, 0] / Xc[:, 2] + 800, 1200 * Xc[:, 1] / Xc[:, 2] + 600], 1)
+    prob.obs_cam = np.concatenate([prob.obs_cam, np.arange(300, dtype=np.int32)]); prob.obs_pt = np.concatenate([prob.obs_pt, np.zeros(300, np.int32)])
+    prob.obs_xy = np.concatenate([prob.obs_xy, uv])
     with capi.BAHandle(prob.copy()) as h:
         t = tables(h)
         assert t["built_on_device"][0] == 0
