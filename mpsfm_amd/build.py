@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmpsfm_hip.so")
-SOURCES = ["ba_kernels.hip", "sweep_dense.hip", "build_dev.hip", "dense_chol.hip", "ba_solver.hip", "tri_kernels.hip", "int_kernels.hip", "prior_kernels.hip", "triangulator.hip", "chol_plan.hip"]
-HEADERS = ["common.h", "devbuild.h", "sweep_common.h", "tri_math.h", "chol_plan.h", os.path.join("..", "..", "include", "mpsfm_hip.h")]
+SOURCES = ["ba_kernels.hip", "sweep_dense.hip", "local_lm.hip", "build_dev.hip", "dense_chol.hip", "ba_solver.hip", "tri_kernels.hip", "int_kernels.hip", "prior_kernels.hip", "triangulator.hip", "chol_plan.hip"]
+HEADERS = ["common.h", "devbuild.h", "sweep_common.h", "sweep_dense_body.h", "sweep_update_body.h", "dense_tile.h", "lm_decide.h", "local_lm.h", "tri_math.h", "chol_plan.h", os.path.join("..", "..", "include", "mpsfm_hip.h")]
 
 
 def _hipcc() -> str:

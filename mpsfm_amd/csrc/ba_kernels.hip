@@ -11,6 +11,8 @@
 //                   landmarks and the candidate cost in one pass over the same chunks.
 #include "common.h"
 #include "sweep_common.h"
+#include "sweep_update_body.h"
+#include "lm_decide.h"
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
@@ -329,132 +331,8 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 __global__ __launch_bounds__(kThreads, 5) void k_update_sweep(SweepArgs A) {
   if (lm_over(A.ctl)) return;
   const double lm_radius = A.ctl ? lm_radius_of(A.ctl) : A.radius;
-  // kLmCopies copies of the landmark accumulators, chosen by the record's camera: the records of a landmark are neighbouring
-  // lanes, and same-address LDS atomics serialise
-  constexpr int kLmCopies = 3, kVCopy = kPtsMax * 6 + 2, kGCopy = kPtsMax * 3 + 2;
-  __shared__ double s_V[kLmCopies * kVCopy];
-  __shared__ double s_g[kLmCopies * kGCopy];   // g_p + W^T y_c, then y_p
-  __shared__ double s_x2[kPtsMax * 3];  // candidate landmark
-  __shared__ int32_t s_slot[kLocalCamsMax];
-  __shared__ double s_red[5 * (kThreads / 64)];
-
-  const int tid = threadIdx.x;
-  const ChunkHdr H = A.chunks[blockIdx.x];
-  const int nrec = H.nrec, npt = H.npt, ncam = H.ncam;
-  for (int i = tid; i < kLmCopies * kVCopy; i += kThreads) s_V[i] = 0.0;
-  for (int i = tid; i < kLmCopies * kGCopy; i += kThreads) s_g[i] = 0.0;
-  if (tid < ncam) s_slot[tid] = A.chunk_cams[H.cam0 + tid];
-  __syncthreads();
-
-  RecUpd L;
-  double mrow[3] = {0, 0, 0};
-  uint32_t meta = 0;
-  int cam = 0, lpt = 0;
-  double2 xy = {0, 0};
-  double d = 1.0, m = 0.0, a = 1.0;
-  bool ok = true;
-  if (tid < nrec) {
-    const int rix = H.rec0 + tid;
-    meta = A.rec_meta[rix];
-    cam = A.rec_cam[rix];
-    const int lcam = meta & 0xff;
-    const int copy = lcam % kLmCopies;
-    lpt = (meta >> 8) & 0xff;
-    xy = reinterpret_cast<const double2*>(A.rec_xy)[rix];
-    if (meta & kRecHasDepth) { d = A.rec_d[rix]; m = A.rec_m[rix]; a = A.rec_a[rix]; }
-    const int pix = H.pt0 + lpt;
-    const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
-    const double psc[3] = {A.ps[3 * pix], A.ps[3 * pix + 1], A.ps[3 * pix + 2]};
-    linearize_update(A.camtab + (size_t)cam * kCamRec, X, psc, meta, xy.x, xy.y, d, m, a, A.loss,
-                     lcam != (int)kLcamConst ? A.yc + (size_t)s_slot[lcam] * 6 : nullptr, L);
-    ok = L.ok;
-    if (L.ok) {
-      mrow[0] = L.mrow[0]; mrow[1] = L.mrow[1]; mrow[2] = L.mrow[2];
-      if (psc[0] != 0.0) {
-        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const double j0 = L.Jp[3 * r], j1 = L.Jp[3 * r + 1], j2 = L.Jp[3 * r + 2];
-          V[0] += j0 * j0; V[1] += j0 * j1; V[2] += j0 * j2; V[3] += j1 * j1; V[4] += j1 * j2; V[5] += j2 * j2;
-          const double rr = L.r[r] + mrow[r];
-          g[0] += j0 * rr; g[1] += j1 * rr; g[2] += j2 * rr;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&s_V[copy * kVCopy + lpt * 6 + k], V[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) atomicAdd(&s_g[copy * kGCopy + lpt * 3 + k], g[k]);
-      }
-    }
-  }
-  __syncthreads();
-
-  double step_sq = 0.0, xn_sq = 0.0;
-  if (tid < npt) {
-    const int pix = H.pt0 + tid;
-    const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
-    double yp[3] = {0, 0, 0}, X2[3] = {X[0], X[1], X[2]};
-    if (A.pt_kv[pix] != 0xffff) {
-      double V[6], Vi[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        V[k] = s_V[tid * 6 + k];
-#pragma unroll
-        for (int q = 1; q < kLmCopies; ++q) V[k] += s_V[q * kVCopy + tid * 6 + k];
-      }
-      V[0] += fmin(fmax(V[0], A.min_diag), A.max_diag) / lm_radius;
-      V[3] += fmin(fmax(V[3], A.min_diag), A.max_diag) / lm_radius;
-      V[5] += fmin(fmax(V[5], A.min_diag), A.max_diag) / lm_radius;
-      if (!spd3_inverse(V, Vi)) {
-        ok = false;
-      } else {
-        double gs[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          gs[k] = s_g[tid * 3 + k];
-#pragma unroll
-          for (int q = 1; q < kLmCopies; ++q) gs[k] += s_g[q * kGCopy + tid * 3 + k];
-        }
-        sym3_mul(Vi, -gs[0], -gs[1], -gs[2], yp);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double dl = A.ps[3 * pix + k] * yp[k];
-          X2[k] = X[k] + dl;
-          step_sq += dl * dl;
-          xn_sq += X2[k] * X2[k];
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      s_g[tid * 3 + k] = yp[k];
-      s_x2[tid * 3 + k] = X2[k];
-      A.pts2[3 * pix + k] = X2[k];
-    }
-  }
-  __syncthreads();
-
-  double mcc = 0.0, cand = 0.0;
-  if (tid < nrec && ok) {
-    const double y0 = s_g[lpt * 3], y1 = s_g[lpt * 3 + 1], y2 = s_g[lpt * 3 + 2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const double mm = mrow[r] + L.Jp[3 * r] * y0 + L.Jp[3 * r + 1] * y1 + L.Jp[3 * r + 2] * y2;
-      mcc -= mm * (L.r[r] + 0.5 * mm);
-    }
-    const double X2[3] = {s_x2[lpt * 3], s_x2[lpt * 3 + 1], s_x2[lpt * 3 + 2]};
-    bool ok2 = true;
-    cand = record_cost(A.camtab2 + (size_t)cam * kCamRec, X2, meta, xy.x, xy.y, d, m, a, A.loss, ok2);
-    if (!ok2) { ok = false; cand = 0.0; }
-  }
-  const double r0 = wave_sum(cand), r1 = wave_sum(ok ? 0.0 : 1.0), r2 = wave_sum(mcc), r3 = wave_sum(step_sq),
-               r4 = wave_sum(xn_sq);
-  const int w = tid >> 6;
-  if ((tid & 63) == 0) { s_red[w] = r0; s_red[4 + w] = r1; s_red[8 + w] = r2; s_red[12 + w] = r3; s_red[16 + w] = r4; }
-  __syncthreads();
-  if (tid < 5) {
-    const double* s = &s_red[4 * tid];
-    A.part2[(size_t)blockIdx.x * 8 + tid] = (s[0] + s[1]) + (s[2] + s[3]);
-  }
+  __shared__ UpdLds S;
+  update_sweep_chunk<false>(A, blockIdx.x, lm_radius, nullptr, nullptr, A.yc, S);
 }
 
 // decode q in [0, k(k+1)/2) -> (i, j), i <= j < k, row-major upper triangle
@@ -928,79 +806,6 @@ __global__ __launch_bounds__(64) void k_lm_decide(LmCtl* C, const double* sc, Lm
   __syncthreads();  // one workgroup: the barrier's workgroup-scope release / acquire orders thread 0's stores before the copy
   // the host's copy of the block goes straight into its pinned slot (device-visible host memory): no copy command in the loop
   if (host_copy) lm_copy_to_host(C, host_copy);
-}
-// The head of the block and the iteration's scalars are pulled into registers first and the head is written back once: as a
-// chain of dependent global loads and stores the same logic took ~15 us.
-__device__ __forceinline__ void lm_decide_logic(LmHead& L, LmCtl* C, const double (&sc)[U_COUNT], const LmOpts& o) {
-  auto trace = [&](double cost, double rad, int acc) {
-    if (L.trace_len < MPSFM_MAX_TRACE) {
-      C->trace_cost[L.trace_len] = cost; C->trace_radius[L.trace_len] = rad; C->trace_accepted[L.trace_len] = (uint8_t)acc; L.trace_len++;
-    }
-  };
-  auto next = [&]() {  // the tests at the top of the next iteration
-    if (L.term != kLmRunning) return;
-    if (L.iter >= o.max_iterations) L.term = MPSFM_TERM_MAX_ITERATIONS;
-    else if (L.radius <= o.min_radius) L.term = MPSFM_TERM_MIN_RADIUS;
-  };
-  L.accepted = 0;
-  L.iter += 1; L.n_jac_evals += 1; L.n_cost_evals += 1;
-  const int chol_fail = sc[U_CHOL_FAIL] != 0.0 ? 1 : 0;
-  L.last_chol_fail = chol_fail;
-  const double x_cost = sc[U_X_COST];
-  const bool x_bad = sc[U_X_BAD] > 0.0;  // residual not evaluable or a landmark block not positive definite
-  L.last_x_cost = x_cost;
-  if (L.iter == 1) {
-    if (!isfinite(x_cost) || x_bad) { L.term = kLmNumericError; return; }
-    L.initial_cost = x_cost + L.fixed_cost;
-    L.cur_cost = x_cost;
-    trace(x_cost + L.fixed_cost, L.radius, 1);
-  }
-  if (L.check_gradient) {  // Ceres checks the gradient tolerance at iteration 0 and after each successful step
-    L.check_gradient = 0;
-    const double gmax = fmax(sc[U_GMAX_CAMS], sc[U_GMAX_PTS]);
-    if (gmax <= o.gradient_tolerance) { L.term = MPSFM_TERM_GRADIENT_TOLERANCE; L.iter -= 1; L.n_cost_evals -= 1; return; }
-  }
-  if (L.iter == 1) {  // the iteration and radius limits are looked at after iteration 0 (cost and gradient at the start) was evaluated
-    if (o.max_iterations <= 0) { L.term = MPSFM_TERM_MAX_ITERATIONS; L.iter = 0; L.n_cost_evals -= 1; return; }
-    if (L.radius <= o.min_radius) { L.term = MPSFM_TERM_MIN_RADIUS; L.iter = 0; L.n_cost_evals -= 1; return; }
-  }
-  const double mcc = sc[U_MCC];
-  L.last_mcc = mcc;
-  const bool solver_ok = !x_bad && chol_fail == 0 && isfinite(mcc);
-  if (!(solver_ok && mcc > 0.0)) {
-    L.invalid_run += 1; L.n_unsuccess += 1;
-    if (L.invalid_run >= o.max_invalid_steps) L.term = MPSFM_TERM_INVALID_STEPS;
-    L.radius /= L.decrease_factor; L.decrease_factor *= 2.0;
-    trace(L.cur_cost + L.fixed_cost, L.radius, 0);
-    L.last_cand = DBL_MAX; L.last_rel = 0.0; L.last_step_norm = 0.0;
-    next();
-    return;
-  }
-  L.invalid_run = 0;
-  const double cand = (sc[U_BAD] > 0.0 || !isfinite(sc[U_CAND_COST])) ? DBL_MAX : sc[U_CAND_COST];
-  const double step_norm = sqrt(sc[U_STEP_SQ_PTS] + sc[U_STEP_SQ_CAMS]);
-  L.last_cand = cand; L.last_step_norm = step_norm;
-  if (step_norm <= o.parameter_tolerance * (L.x_norm + o.parameter_tolerance)) { L.term = MPSFM_TERM_PARAMETER_TOLERANCE; return; }
-  const double cost_change = x_cost - cand;
-  if (fabs(cost_change) <= o.function_tolerance * x_cost) { L.term = MPSFM_TERM_FUNCTION_TOLERANCE; return; }
-  const double rel = cost_change / mcc;
-  L.last_rel = rel;
-  if (rel > o.min_relative_decrease) {
-    L.accepted = 1;
-    L.x_norm = sqrt(sc[U_XN_SQ_PTS] + sc[U_XN_SQ_CAMS]);
-    L.cur_cost = cand;
-    const double u = 2.0 * rel - 1.0;
-    L.radius = fmin(o.max_radius, L.radius / fmax(1.0 / 3.0, 1.0 - u * u * u));
-    L.decrease_factor = 2.0;
-    L.n_success += 1;
-    L.check_gradient = 1;
-    trace(cand + L.fixed_cost, L.radius, 1);
-  } else {
-    L.radius /= L.decrease_factor; L.decrease_factor *= 2.0;
-    L.n_unsuccess += 1;
-    trace(L.cur_cost + L.fixed_cost, L.radius, 0);
-  }
-  next();
 }
 __device__ __forceinline__ void lm_decide_thread(LmCtl* C, const double* scal, const LmOpts& o) {
   double sc[U_COUNT];

@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "devbuild.h"
+#include "local_lm.h"
 
 namespace mpsfm {
 
@@ -487,6 +488,12 @@ struct mpsfm_ba_handle {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double last_radius = 1e4;
   bool scales_ready = false;
+  // single-launch solver of small problems (local_lm.hip): two accumulators | barrier words + clocks | per-iteration heads
+  bool local_ok = false;
+  double* d_local_acc = nullptr;
+  int64_t* d_local_sync = nullptr;   // [0]: two 32-bit barrier words, [1..4]: phase clocks
+  LmHead* d_local_log = nullptr;
+  int local_log_cap = 0;
 };
 
 namespace mpsfm {
@@ -505,6 +512,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl, h->d_slab, h->d_red_dests, h->d_red_srcs,
                   h->d_sky_first, h->d_sky_start, h->d_sky_index,
+                  h->d_local_acc, h->d_local_sync, h->d_local_log,
                   h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm, h->d_lp_live, h->d_lp_col_slot};
   for (void* p : ptrs) cached_free(p);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
@@ -1721,6 +1729,20 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     for (auto& e : h->ov.evF) HIP_TRY(pooled_event(&e, false));
     for (auto& e : h->ov.evB) HIP_TRY(pooled_event(&e, false));
   }
+  // Small problems (local bundle adjustment): the whole trust-region loop in one cooperative launch, one workgroup per chunk
+  h->local_ok = false;
+  {
+    const char* e = std::getenv("MPSFM_LOCAL_LM");
+    const bool wanted = !(e && std::atoi(e) == 0);
+    if (wanted && !sharded(h) && h->nlong == 0 && h->nchunks > 0 && h->n_dense == h->nchunks && h->ncv >= 1 && h->ncv <= kLocalCams &&
+        h->n_user == 6 * h->ncv && h->nchunks <= local_lm_max_chunks(h->device)) {
+      h->local_log_cap = std::max(h->opt.max_num_iterations, 0) + 2;
+      if ((rc = dev_alloc(&h->d_local_acc, (size_t)2 * kLocalAccDoubles))) return rc;
+      if ((rc = dev_alloc(&h->d_local_sync, (size_t)16))) return rc;
+      if ((rc = dev_alloc(&h->d_local_log, (size_t)h->local_log_cap))) return rc;
+      h->local_ok = true;
+    }
+  }
   HIP_TRY(hipMemsetAsync(h->d_ps, 0, nps * 3 * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(h->d_yc, 0, (size_t)std::max(h->n_user, 1) * sizeof(double), h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1860,6 +1882,90 @@ static int run_dense(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullp
   return 0;
 }
 
+// Small problems (local bundle adjustment): fixed cost, column scales, the trust-region loop and the state norm without a single
+// host synchronisation before the end — the loop is ONE cooperative launch (local_lm.hip).  Returns kLocalRefused when the launch
+// is not accepted (nothing has changed the state then: the launch chain takes over).
+constexpr int kLocalRefused = 1;
+static int solve_local(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
+  hipStream_t s = h->stream;
+  const mpsfm_ba_options& o = h->opt;
+  launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 0, h->d_cs, s);
+  launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, s);
+  double* fixed_parts = h->d_scal + 12;  // three free slots of the scalar block
+  HIP_TRY(hipMemsetAsync(h->d_scal, 0, sizeof(double) * U_COUNT, s));
+  if (h->nfixed > 0) {
+    const int nb = (int)std::min<int64_t>(1024, (h->nfixed + kThreads - 1) / kThreads);
+    CostArgs c{h->nfixed, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d, h->d_fx_m, h->d_fx_a, h->d_camtab, h->d_pts, h->loss, h->d_costpart};
+    launch_cost_records(c, nb, s);
+    launch_reduce_cols(h->d_costpart, nb, 4, 3, 0u, fixed_parts, s);
+  }
+  if (int rc = prepare_scales(h)) return rc;
+  LmCtl c0;
+  std::memset(&c0, 0, sizeof(c0));
+  c0.radius = o.initial_trust_region_radius; c0.decrease_factor = 2.0;
+  c0.term = kLmRunning; c0.check_gradient = 1;  // x_norm and fixed_cost: filled in by the launch
+  h->h_ctl[0] = c0;
+  HIP_TRY(hipMemcpyAsync(h->d_ctl, &h->h_ctl[0], sizeof(LmCtl), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(h->d_local_acc, 0, sizeof(double) * 2 * kLocalAccDoubles, s));
+  HIP_TRY(hipMemsetAsync(h->d_local_sync, 0, sizeof(int64_t) * 16, s));
+  LocalArgs la{};
+  la.A = sweep_args(h, 0.0, nullptr);
+  la.ctl = h->d_ctl;
+  la.o = LmOpts{o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.min_relative_decrease, o.max_trust_region_radius,
+                o.min_trust_region_radius, o.max_num_iterations, o.max_num_consecutive_invalid_steps};
+  la.log = o.verbose > 0 ? h->d_local_log : nullptr;
+  la.acc[0] = h->d_local_acc; la.acc[1] = h->d_local_acc + kLocalAccDoubles;
+  la.bar = reinterpret_cast<int32_t*>(h->d_local_sync); la.clk = reinterpret_cast<long long*>(h->d_local_sync + 1);
+  la.ncv = h->ncv; la.nc = h->nc; la.nchunks = h->nchunks;
+  la.q = h->d_q; la.t = h->d_t; la.camtab = h->d_camtab; la.pts = h->d_pts; la.cs = h->d_cs; la.fixed_parts = fixed_parts;
+  if (launch_local_lm(la, s) != (int)hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(hipStreamSynchronize(s));  // the pinned control block is free again
+    return kLocalRefused;
+  }
+  static_assert(sizeof(int64_t) * 8 <= sizeof(double) * U_COUNT * 2, "the pinned scalar block holds the sync words");
+  int64_t* hs = reinterpret_cast<int64_t*>(h->h_scal);
+  HIP_TRY(hipMemcpyAsync(&h->h_ctl[0], h->d_ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hs, h->d_local_sync, sizeof(int64_t) * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  if (reinterpret_cast<const int32_t*>(hs)[1] != 0)
+    return fail(MPSFM_EHIP, "single-launch solver: a grid barrier did not complete (workgroups not co-resident?); MPSFM_LOCAL_LM=0 selects the launch chain");
+  const LmCtl& last = h->h_ctl[0];
+  const double fixed = last.fixed_cost;
+  sum->fixed_cost = fixed;
+  sum->time_linearize_s = 1e-8 * (double)(hs[1] + hs[2]); sum->time_dense_s = 1e-8 * (double)hs[3]; sum->time_update_s = 1e-8 * (double)(hs[4] + hs[5] + hs[6]);
+  if (o.verbose > 0) {
+    const int nlog = std::min(last.iter + 1, h->local_log_cap);
+    std::vector<LmHead> log((size_t)std::max(nlog, 0));
+    if (nlog > 0) HIP_TRY(hipMemcpy(log.data(), h->d_local_log, sizeof(LmHead) * (size_t)nlog, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nlog; ++i) {
+      const LmHead& l = log[(size_t)i];
+      if (l.iter != i + 1 && i != nlog - 1) continue;
+      if (l.last_mcc > 0.0 && l.last_cand != DBL_MAX)
+        std::fprintf(stderr, "[mpsfm_ba] it %3d cost %.9e cand %.9e rel %.3e radius %.3e |step| %.3e\n", i + 1, l.last_x_cost + fixed, l.last_cand + fixed,
+                     l.last_rel, l.radius, l.last_step_norm);
+      else
+        std::fprintf(stderr, "[mpsfm_ba] it %3d invalid step (chol_fail=%d mcc=%.3e) radius %.3e\n", i + 1, l.last_chol_fail, l.last_mcc, l.radius);
+    }
+  }
+  h->last_radius = last.radius;
+  sum->num_jacobian_evals = last.n_jac_evals;
+  sum->num_residual_evals = (int64_t)h->nblocks_reduced_global * ((int64_t)last.n_cost_evals + last.n_jac_evals);
+  if (last.term == kLmNumericError)
+    return fail(MPSFM_ENUMERIC, "the initial point cannot be evaluated (non-finite residual or depth <= 0 in a log-depth block)");
+  sum->initial_cost = last.initial_cost;
+  sum->final_cost = last.cur_cost + fixed;
+  sum->num_iterations = last.iter;
+  sum->num_successful_steps = last.n_success;
+  sum->num_unsuccessful_steps = last.n_unsuccess;
+  sum->termination = last.term;
+  sum->final_radius = last.radius;
+  sum->trace_len = last.trace_len;
+  for (int i = 0; i < last.trace_len; ++i) { sum->trace_cost[i] = last.trace_cost[i]; sum->trace_radius[i] = last.trace_radius[i]; sum->trace_accepted[i] = last.trace_accepted[i]; }
+  return 0;
+}
+
 static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   using clk = std::chrono::steady_clock;
   HIP_TRY(hipSetDevice(h->device));
@@ -1871,6 +1977,13 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   sum->num_residual_blocks = (int64_t)h->nblocks_global;
   sum->reduced_dim = h->n_user;
   int64_t n_cost_evals = 0, n_jac_evals = 0;
+  if (h->local_ok) {
+    const int rc = solve_local(h, sum);
+    if (rc != kLocalRefused) {
+      sum->time_total_s = std::chrono::duration<double>(clk::now() - t_begin).count();
+      return rc;
+    }
+  }
 
   // camera table at the initial point (unit scales) for the fixed cost
   launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 0, h->d_cs, s);
@@ -2342,6 +2455,7 @@ int64_t mpsfm_debug_table(mpsfm_ba_handle* h, int32_t which, void* out, int64_t 
     case 23: src = h->d_blk_desc; bytes = 4 * h->n_blk_desc; break;
     case 24: src = h->d_blk_ent_start; bytes = 4 * h->n_blk_ent_start; break;
     case 25: src = h->d_ents; bytes = 4 * h->n_ents; break;
+    case 26: src = h->d_part; bytes = 32 * (int64_t)h->nchunks; break;
     case 22: { static uint8_t flag; flag = h->built_on_device ? 1 : 0; src = &flag; bytes = 1; host = true; break; }
     default: return fail(MPSFM_EINVAL, "unknown table");
   }
@@ -2363,6 +2477,15 @@ int mpsfm_ba_sweep_parts(mpsfm_ba_handle* h, float ms[3], int64_t info[4]) {
   return 0;
 }
 
+// phase clocks of the last single-launch solve (local_lm.hip), 100 MHz ticks: sweep, barrier 1, dense + cameras, update, barrier 2,
+// decision, iterations, then (debug flag 64 << 8) inside the dense phase: assemble, stacked factorisations, their barrier, trailing
+// updates, back substitution; returns 0 when the handle does not take that path
+int mpsfm_debug_local_clocks(mpsfm_ba_handle* h, int64_t out[12]) {
+  if (!h || !h->local_ok) return 0;
+  if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return 0;
+  if (hipMemcpy(out, h->d_local_sync + 1, sizeof(int64_t) * 12, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return 1;
+}
 int mpsfm_ba_dense_solve_once(mpsfm_ba_handle* h, float* elapsed_ms) {
   if (!h) return fail(MPSFM_EINVAL, "handle is NULL");
   HIP_TRY(hipSetDevice(h->device));

@@ -29,6 +29,7 @@ namespace mpsfm {
 
 // ---- track-sweep chunk geometry ----------------------------------------------------------
 // A chunk = a group of consecutive (re-ordered) landmarks processed by one workgroup.
+typedef double v4d __attribute__((ext_vector_type(4)));  // accumulators of v_mfma_f64_16x16x4_f64
 constexpr int kThreads = 256;   // workgroup size of the sweep kernels
 constexpr int kObsMax = MPSFM_OBS_MAX;    // merged (camera, landmark) records per chunk
 constexpr int kPtsMax = MPSFM_OBS_MAX / 2;     // landmarks per chunk

@@ -195,6 +195,23 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// camera table row of a record: the table in HBM, or (kLocal: single-launch solver) the workgroup's own LDS copy of the variable
+// cameras, indexed by slot
+template <bool kLocal>
+__device__ __forceinline__ const double* camera_row(const double* tab, const double* l_tab, const int32_t* slot, int cam, int lcam) {
+  if constexpr (kLocal) { if (lcam != (int)kLcamConst) return l_tab + slot[lcam] * kCamRec; }
+  return tab + (size_t)cam * kCamRec;
+}
+
+// threadIdx.x; kOpaque: behind an empty asm, so that inside a loop over LM iterations (local_lm.hip) nothing derived from it is
+// hoisted out of the loop and kept alive across every phase
+template <bool kOpaque>
+__device__ __forceinline__ int thread_index() {
+  int t = threadIdx.x;
+  if constexpr (kOpaque) asm volatile("" : "+v"(t));
+  return t;
+}
+
 enum { MODE_FULL = 0, MODE_DIAG = 1 };
 
 }  // namespace mpsfm

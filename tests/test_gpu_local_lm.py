@@ -1,0 +1,169 @@
+"""The single-launch solver of small problems (csrc/local_lm.hip: the whole Levenberg-Marquardt loop of a local bundle adjustment in
+one cooperative launch) against the launch chain it replaces for such problems (MPSFM_LOCAL_LM=0) and against the CPU oracle:
+same decisions, same traces, same final state; and the problems it must leave to the chain."""
+
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from mpsfm_amd import capi
+from mpsfm_amd.synthetic import local_window, make_scene
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def local_iterations(h) -> int:
+    """Iterations the handle's last solve ran inside the single launch; -1: the handle does not take that path."""
+    L = capi.lib()
+    L.mpsfm_debug_local_clocks.argtypes = [C.c_void_p, C.c_void_p]
+    L.mpsfm_debug_local_clocks.restype = C.c_int
+    clk = (C.c_int64 * 12)()
+    return int(clk[6]) if L.mpsfm_debug_local_clocks(h._h, clk) else -1
+
+
+def solve_resident(prob, monkeypatch, local, options=None):
+    if local:
+        monkeypatch.delenv("MPSFM_LOCAL_LM", raising=False)
+    else:
+        monkeypatch.setenv("MPSFM_LOCAL_LM", "0")
+    out = prob.copy()
+    with capi.BAHandle(prob.copy(), options=options) as h:
+        s = h.solve()
+        h.get_state(out)
+        its = local_iterations(h)
+    monkeypatch.delenv("MPSFM_LOCAL_LM", raising=False)
+    return s, out, its
+
+
+def assert_same_solve(sa, pa, sb, pb, rtol=1e-10):
+    assert sa["termination"] == sb["termination"]
+    assert sa["num_iterations"] == sb["num_iterations"]
+    assert sa["num_successful_steps"] == sb["num_successful_steps"]
+    assert sa["initial_cost"] == pytest.approx(sb["initial_cost"], rel=1e-13)
+    assert sa["final_cost"] == pytest.approx(sb["final_cost"], rel=rtol)
+    np.testing.assert_allclose(sa["trace_cost"], sb["trace_cost"], rtol=rtol)
+    np.testing.assert_allclose(sa["trace_radius"], sb["trace_radius"], rtol=1e-6)  # (the radius rule cubes the gain ratio)
+    assert list(sa["trace_accepted"]) == list(sb["trace_accepted"])
+    np.testing.assert_allclose(pa.pts, pb.pts, atol=1e-9)
+    np.testing.assert_allclose(pa.cam_t, pb.cam_t, atol=1e-9)
+    np.testing.assert_allclose(np.abs(np.sum(pa.cam_quat * pb.cam_quat, axis=1)), 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("ncam,npts,depth", [(3, 300, True), (6, 1500, True), (7, 900, False), (12, 4000, True), (16, 6000, True), (17, 3000, True)])
+def test_single_launch_solve_equals_the_launch_chain(ncam, npts, depth, monkeypatch):
+    """One, two and three tile columns of the reduced system (the first camera is the gauge: 17 cameras are 16 variable ones)."""
+    prob = make_scene(ncam, npts, depth, seed=5)[0]
+    sc, pc, ic = solve_resident(prob, monkeypatch, False)
+    sl, pl, il = solve_resident(prob, monkeypatch, True)
+    assert ic == -1 and il == sl["num_iterations"] > 3
+    assert_same_solve(sl, pl, sc, pc)
+
+
+def test_single_launch_solve_equals_the_oracle(monkeypatch):
+    prob = make_scene(10, 2500, True, seed=8)[0]
+    po = prob.copy()
+    so = O.solve(po)
+    sl, pl, il = solve_resident(prob, monkeypatch, True)
+    assert il == sl["num_iterations"]
+    assert sl["initial_cost"] == pytest.approx(so["initial_cost"], rel=1e-12)
+    assert sl["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8)
+    assert sl["num_iterations"] == so["num_iterations"] and sl["termination"] == so["termination"]
+    n = min(len(sl["trace_cost"]), len(so["trace_cost"]))
+    np.testing.assert_allclose(sl["trace_cost"][:n], so["trace_cost"][:n], rtol=1e-9)
+    np.testing.assert_allclose(pl.pts, po.pts, atol=1e-6)
+    np.testing.assert_allclose(pl.cam_t, po.cam_t, atol=1e-6)
+
+
+def test_single_launch_solve_of_a_local_window(monkeypatch):
+    """The problem Optimizer.ba(mode='local') builds: constant cameras outside the window, constant landmarks, fixed blocks."""
+    base = make_scene(40, 9000, True, seed=6)[0]
+    loc = local_window(base, window_cams=[10, 11, 12, 13, 14, 15], ref_cam=15)[0]
+    assert int((loc.pose_const == 0).sum()) == 5 and int(loc.pose_const.sum()) > 1 and int(loc.pt_const.sum()) > 0
+    sc, pc, ic = solve_resident(loc, monkeypatch, False)
+    sl, pl, il = solve_resident(loc, monkeypatch, True)
+    assert ic == -1 and il == sl["num_iterations"]
+    assert_same_solve(sl, pl, sc, pc)
+    po = loc.copy()
+    so = O.solve(po)
+    assert sl["final_cost"] == pytest.approx(so["final_cost"], rel=1e-8) and sl["num_iterations"] == so["num_iterations"]
+    np.testing.assert_array_equal(pl.cam_quat[loc.pose_const != 0], loc.cam_quat[loc.pose_const != 0])
+    np.testing.assert_array_equal(pl.pts[loc.pt_const != 0], loc.pts[loc.pt_const != 0])
+
+
+def test_rejected_steps_and_the_iteration_limit(monkeypatch):
+    """A start far from the optimum with a large initial radius: steps are rejected, the radius shrinks, the limit ends the solve."""
+    prob = make_scene(8, 1200, False, seed=13)[0]
+    rng = np.random.default_rng(3)
+    prob.pts += rng.normal(0, 0.3, prob.pts.shape)
+    q = prob.cam_quat[1:] + rng.normal(0, 0.25, prob.cam_quat[1:].shape)
+    prob.cam_quat[1:] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    o = capi.default_options(initial_trust_region_radius=1e16, max_num_iterations=15)
+    so = O.solve(prob.copy(), O.default_options(initial_trust_region_radius=1e16, max_num_iterations=15))
+    assert so["trace_accepted"].count(0) >= 3, "the scene is meant to produce rejected steps"
+    sc, pc, _ = solve_resident(prob, monkeypatch, False, o)
+    sl, pl, il = solve_resident(prob, monkeypatch, True, o)
+    assert il == sl["num_iterations"]
+    assert list(sl["trace_accepted"]) == list(so["trace_accepted"]) and sl["termination"] == so["termination"]
+    np.testing.assert_allclose(sl["trace_cost"], so["trace_cost"], rtol=1e-7)
+    assert_same_solve(sl, pl, sc, pc, rtol=1e-8)
+    for o in (capi.default_options(max_num_iterations=0), capi.default_options(max_num_iterations=1)):
+        sc, pc, _ = solve_resident(prob, monkeypatch, False, o)
+        sl, pl, _ = solve_resident(prob, monkeypatch, True, o)
+        assert_same_solve(sl, pl, sc, pc, rtol=1e-9)
+
+
+def test_second_solve_starts_at_the_optimum(monkeypatch):
+    """solve() twice on one handle: the second one meets a tolerance at once, the state stays."""
+    prob = make_scene(6, 800, True, seed=4)[0]
+    out1, out2 = prob.copy(), prob.copy()
+    with capi.BAHandle(prob.copy()) as h:
+        s1 = h.solve()
+        h.get_state(out1)
+        s2 = h.solve()
+        h.get_state(out2)
+        assert local_iterations(h) == s2["num_iterations"]
+    assert s2["num_iterations"] <= 2 and s2["initial_cost"] == pytest.approx(s1["final_cost"], rel=1e-12)
+    np.testing.assert_allclose(out2.pts, out1.pts, atol=1e-6)
+
+
+def test_problems_the_single_launch_leaves_to_the_chain(monkeypatch):
+    # more than 16 variable cameras
+    with capi.BAHandle(make_scene(18, 3000, True, seed=1)[0]) as h:
+        h.solve()
+        assert local_iterations(h) == -1
+    # a landmark with a track beyond a chunk's camera list: general chunks
+    monkeypatch.setenv("MPSFM_SWEEP_DENSE", "0")
+    with capi.BAHandle(make_scene(8, 1000, True, seed=1)[0]) as h:
+        h.solve()
+        assert local_iterations(h) == -1
+    monkeypatch.delenv("MPSFM_SWEEP_DENSE")
+    # every pose constant: no reduced system
+    p = make_scene(6, 300, True, seed=2)[0]
+    p.pose_const[:] = 1
+    p.gauge_axis_cam = -1
+    with capi.BAHandle(p) as h:
+        h.solve()
+        assert local_iterations(h) == -1
+
+
+def test_concurrent_single_launch_solves():
+    """Cooperative launches from several host threads and streams: every solve equals its sequential result."""
+    probs = [make_scene(5 + i, 700 + 150 * i, True, seed=20 + i)[0] for i in range(4)]
+    want = [capi.ba_solve(p.copy())["final_cost"] for p in probs]
+    got = [[None] * 3 for _ in probs]
+
+    def work(i):
+        for r in range(3):
+            got[i][r] = capi.ba_solve(probs[i].copy())["final_cost"]
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(probs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(len(probs)):
+        for r in range(3):
+            assert got[i][r] == pytest.approx(want[i], rel=1e-11)
