@@ -1853,10 +1853,15 @@ static void launch_sweeps(mpsfm_ba_handle* h, SweepArgs a, hipStream_t s) {
 
 // one track sweep at the current state: fills the reduced buffer and its scalar tail
 // (inside the solve loop the prologue kernel has zeroed the buffer; single-rank runs reduce the partials with the decision)
-static int run_track_sweep(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullptr, bool in_loop = false) {
+static int run_track_sweep(mpsfm_ba_handle* h, double radius, const LmCtl* ctl = nullptr, bool in_loop = false, bool adopt = false) {
   hipStream_t s = h->stream;
   if (!in_loop) launch_zero(h->d_red, h->red_count, ctl, s);
   SweepArgs a = sweep_args(h, radius, ctl);
+  if (adopt) {
+    a.adopt_on = 1; a.adopt_nc = h->nc;
+    a.pts_rw = h->d_pts; a.q_rw = h->d_q; a.t_rw = h->d_t; a.camtab_rw = h->d_camtab; a.q2 = h->d_q2; a.t2 = h->d_t2;
+    a.red = h->d_red; a.nred = h->red_count;
+  }
   launch_sweeps(h, a, s);
   if (h->nchunks + h->nlong > 0 && !(in_loop && !sharded(h)))
     launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, sharded(h) ? nullptr : h->d_scal + U_X_COST);
@@ -2048,11 +2053,15 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
                   o.min_trust_region_radius, o.max_num_iterations, o.max_num_consecutive_invalid_steps};
   const LmCtl* ctl = h->d_ctl;
   const double host_radius = 0.0;  // unused: the kernels read the radius from the control block
+  const bool fuse_prologue = [] { const char* e = std::getenv("MPSFM_FUSE_PROLOGUE"); return !(e && std::atoi(e) == 0); }();
   auto enqueue_iteration = [&](int it) -> int {
     hipEvent_t* ev = (it & 1) ? h->ev2 : h->ev;
     HIP_TRY(hipEventRecord(ev[0], s));
-    launch_lm_prologue(h->d_ctl, h->d_red, h->red_count, h->nc, h->np, h->d_q, h->d_t, h->d_camtab, h->d_pts, h->d_q2, h->d_t2, h->d_camtab2, h->d_pts2, s);
-    if (int rc = run_track_sweep(h, host_radius, ctl, true)) return rc;
+    // all chunks dense and one rank: the dense sweep adopts an accepted candidate and zeroes the reduced buffer itself
+    const bool fused_prologue = fuse_prologue && !sharded(h) && h->nlong == 0 && h->n_dense > 0 && h->n_dense == h->nchunks;
+    if (!fused_prologue)
+      launch_lm_prologue(h->d_ctl, h->d_red, h->red_count, h->nc, h->np, h->d_q, h->d_t, h->d_camtab, h->d_pts, h->d_q2, h->d_t2, h->d_camtab2, h->d_pts2, s);
+    if (int rc = run_track_sweep(h, host_radius, ctl, true, fused_prologue)) return rc;
     if (int rc = allreduce_dev(h, h->d_red, h->red_count)) return rc;
     HIP_TRY(hipEventRecord(ev[1], s));
     if (int rc = run_dense(h, host_radius, ctl)) return rc;

@@ -333,7 +333,14 @@ struct SweepArgs {
   double* pts2;            // candidate landmarks
   double* part2;           // [nchunks][8]
   const LmCtl* ctl;        // inside a solve: trust-region radius and the stop flag live on the device (NULL: `radius` above)
+  // k_track_sweep_dense as the first launch of an iteration (all chunks dense, one rank): what k_lm_prologue would do — an accepted
+  // candidate becomes the state, the reduced buffer starts from zero — is spread over the sweep's workgroups
+  int32_t adopt_on, adopt_nc;
+  double* pts_rw; double* q_rw; double* t_rw; double* camtab_rw;
+  const double* q2; const double* t2;
+  double* red; int64_t nred;
 };
+__device__ inline bool lm_accepted(const LmCtl* c) { return c != nullptr && __hip_atomic_load(&c->accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 
 struct CostArgs {
   int64_t nrec;

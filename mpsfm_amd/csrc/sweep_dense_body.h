@@ -268,6 +268,27 @@ __device__ __forceinline__ void dense_sweep_chunk(const SweepArgs& A, int cix, d
   const int ncopy = ncam <= 8 ? 4 : 2, cstride = ncam <= 8 ? 8 : 16;  // accumulator copies x cameras per copy = 32
 
   // ---- P0 ------------------------------------------------------------------------------------------------------------
+  // first launch of an iteration: the candidate the last decision accepted is what this sweep linearises at; its copy into the
+  // state (this chunk's landmarks; the cameras and the zeroing of the reduced buffer dealt over all workgroups) runs beside P1
+  bool adopt = false;
+  if constexpr (!kLocal) {
+    if (A.adopt_on) {
+      adopt = lm_accepted(A.ctl);
+      const int64_t g0 = (int64_t)(cix - A.chunk0) * kThreads + tid, gstep = (int64_t)A.nchunks * kThreads;
+      for (int64_t e = g0; e < A.nred; e += gstep) A.red[e] = 0.0;
+      if (adopt) {
+        for (int i = tid; i < 3 * npt; i += kThreads) A.pts_rw[(size_t)3 * H.pt0 + i] = A.pts2[(size_t)3 * H.pt0 + i];
+        const int64_t n_q = 4 * (int64_t)A.adopt_nc, n_t = 3 * (int64_t)A.adopt_nc, n_tab = (int64_t)kCamRec * A.adopt_nc;
+        for (int64_t e = g0; e < n_q + n_t + n_tab; e += gstep) {
+          if (e < n_q) A.q_rw[e] = A.q2[e];
+          else if (e < n_q + n_t) A.t_rw[e - n_q] = A.t2[e - n_q];
+          else A.camtab_rw[e - n_q - n_t] = A.camtab2[e - n_q - n_t];
+        }
+      }
+    }
+  }
+  const double* const pts_at = adopt ? A.pts2 : A.pts;
+  const double* const camtab_at = adopt ? A.camtab2 : A.camtab;
   for (int i = tid; i < npt * 6; i += kThreads) S.V[i] = 0.0;
   for (int i = tid; i < npt * 3; i += kThreads) S.g[i] = 0.0;
   for (int i = tid; i < kAccU; i += kThreads) S.U[i] = 0.0;
@@ -297,11 +318,11 @@ __device__ __forceinline__ void dense_sweep_chunk(const SweepArgs& A, int cix, d
     double d = 1.0, m = 0.0, a = 1.0;
     if (meta & kRecHasDepth) { d = A.rec_d[rix]; m = A.rec_m[rix]; a = A.rec_a[rix]; }
     const int pix = H.pt0 + lpt;
-    const double X[3] = {A.pts[3 * pix], A.pts[3 * pix + 1], A.pts[3 * pix + 2]};
+    const double X[3] = {pts_at[3 * pix], pts_at[3 * pix + 1], pts_at[3 * pix + 2]};
     const double psc[3] = {A.ps[3 * pix], A.ps[3 * pix + 1], A.ps[3 * pix + 2]};
     RecLin L;
     if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace[10] = (long long)clock64(); }  // the record / landmark loads have landed (the camera row follows)
-    linearize_record(camera_row<kLocal>(A.camtab, l_tab, S.slot, cam, lcam), X, psc, meta, xy.x, xy.y, d, m, a, A.loss, L);
+    linearize_record(camera_row<kLocal>(camtab_at, l_tab, S.slot, cam, lcam), X, psc, meta, xy.x, xy.y, d, m, a, A.loss, L);
     my_cost = L.cost;
     if (trace) { asm volatile("" : "+v"(L.Jc[0]), "+v"(L.Jp[8]), "+v"(L.cost)); trace[11] = (long long)clock64(); }
     my_bad = L.ok ? 0 : 1;

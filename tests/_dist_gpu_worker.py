@@ -20,7 +20,10 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out = sys.argv[1]
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+
+    # a collective that does not complete raises after two minutes instead of holding the test for gloo's default half hour
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         probe = torch.ones(4, dtype=torch.float64, device="cuda")
         dist.all_reduce(probe)

@@ -375,7 +375,7 @@ def test_two_process_sharded_solve_on_one_gpu(tmp_path, gtol):
                    MPSFM_TEST_GTOL="" if gtol is None else repr(gtol))
         procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), str(seed)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=500) for p in procs]
+    outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     res = [json.load(open(tmp_path / f"r{r}.json")) for r in range(world)]
