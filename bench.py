@@ -85,22 +85,52 @@ def main():
         del full
     else:
         prob, _ = make_config(args.config, seed=0, shard=rank)
-    opts = capi.default_options(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     collective = None
-    if dist is not None:
-        from mpsfm_amd.dist import hook_options, make_torch_allreduce, use_native_rccl
+    alive = []  # the hook's callback object and the options block must outlive the handle
 
-        # default: the library's own RCCL communicator (no Python inside the LM loop); MPSFM_BENCH_COLLECTIVE=hook (or a
-        # non-RCCL rehearsal backend) goes through the torch.distributed hook
-        if backend == "nccl" and os.environ.get("MPSFM_BENCH_COLLECTIVE", "rccl") == "rccl":
-            use_native_rccl(opts)
-            collective = "native RCCL (ncclAllReduce on the solver's stream)"
-        else:
-            fn, keep = make_torch_allreduce()
-            hook_options(opts, fn)
-            collective = f"torch.distributed hook ({backend})"
+    def make_handle(native: bool):
+        opts = capi.default_options(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        name = None
+        if dist is not None:
+            from mpsfm_amd.dist import hook_options, make_torch_allreduce, use_native_rccl
 
-    h = capi.BAHandle(prob, opts)
+            if native:
+                use_native_rccl(opts)
+                name = "native RCCL (ncclAllReduce on the solver's stream)"
+            else:
+                fn, keep = make_torch_allreduce()
+                hook_options(opts, fn)
+                alive.append((fn, keep))
+                name = f"torch.distributed hook ({backend})"
+        alive.append(opts)
+        return capi.BAHandle(prob, opts), name
+
+    # default: the library's own RCCL communicator (no Python inside the LM loop); MPSFM_BENCH_COLLECTIVE=hook (or a non-RCCL
+    # rehearsal backend) goes through the torch.distributed hook.  The native communicator has not run with more than one rank
+    # on the development box (one GPU): its first solve is checked — it must succeed on every rank and every rank must report
+    # the same cost — and the run falls back to the hook when it does not.
+    want_native = dist is not None and backend == "nccl" and os.environ.get("MPSFM_BENCH_COLLECTIVE", "rccl") == "rccl"
+    h = None
+    if want_native:
+        ok, cost = 1.0, 0.0
+        try:
+            h, collective = make_handle(True)
+            cost = float(h.solve()["final_cost"])
+            ok = 1.0 if np.isfinite(cost) and cost > 0.0 else 0.0
+        except Exception as e:  # noqa: BLE001 - any failure of the unverified path selects the verified one
+            print(f"[bench] rank {rank}: native RCCL path failed ({e!r}); falling back to the torch.distributed hook", file=sys.stderr)
+            ok = 0.0
+        chk = torch.tensor([ok, cost, -cost], dtype=torch.float64, device="cuda")
+        dist.all_reduce(chk, op=dist.ReduceOp.MIN)
+        agreed = bool(chk[0].item() == 1.0) and abs(chk[1].item() + chk[2].item()) <= 1e-9 * abs(chk[1].item())  # min(cost) == max(cost)
+        if not agreed:
+            if rank == 0:
+                print("[bench] native RCCL path not confirmed on every rank: using the torch.distributed hook", file=sys.stderr)
+            if h is not None:
+                h.close()
+            h = None
+    if h is None:
+        h, collective = make_handle(False)
 
     def barrier():
         torch.cuda.synchronize()
