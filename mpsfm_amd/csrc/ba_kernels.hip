@@ -904,6 +904,20 @@ __global__ __launch_bounds__(256) void k_lm_accept(const LmCtl* C, int nc, int64
   }
 }
 
+// landmark state between the caller's order and the handle's (chunk) order: dst[k] = src[perm[k]] / dst[perm[k]] = src[k]
+__global__ __launch_bounds__(256) void k_permute_pts(int64_t np, const int32_t* perm, const double* src, double* dst, int scatter) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * np) return;
+  const int64_t k = i / 3, c = i - 3 * k;
+  const int64_t u = 3 * (int64_t)perm[k] + c;
+  if (scatter) dst[u] = src[i];
+  else dst[i] = src[u];
+}
+void launch_permute_pts(int64_t np, const int32_t* perm, const double* src, double* dst, bool scatter, hipStream_t s) {
+  if (np <= 0) return;
+  hipLaunchKernelGGL(k_permute_pts, dim3((unsigned)((3 * np + 255) / 256)), dim3(256), 0, s, np, perm, src, dst, scatter ? 1 : 0);
+}
+
 // ---- launch wrappers ------------------------------------------------------------------------------
 void init_tile_tables(hipStream_t) {}
 

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64) void k_cut(int np_chunked, int nseg, int W, con
   if (lane == 0) { seg_nchunks[sidx] = nchunks; seg_ncams[sidx] = ncams; }
 }
 
-// ---- the chunk cut for camera sets of up to 512 slots (W <= 8 words), without the sequential walk over the landmarks -----------
+// ---- the chunk cut for camera sets of up to 1024 slots (W <= 16 words), without the sequential walk over the landmarks -----------
 // The greedy cut is a chain: a chunk that starts at landmark k ends at next(k), which depends on the landmarks from k on only.  So
 // next(k) is computed for EVERY k in parallel (one thread walks the ~50 landmarks of the chunk that would start there, the camera
 // set in W registers), and the segment's chunks are the chain k0 -> next(k0) -> ... followed by one thread per segment (~75 hops).
@@ -722,7 +722,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   int nslots = 0;
   for (int32_t v : slot_of_cam) nslots = std::max(nslots, v + 1);
   const int W = std::max(1, (nslots + 63) / 64);
-  const bool jump = W <= 8;  // camera sets of up to 512 slots: the parallel form (k_next / k_walk); beyond: one wave per segment (k_cut)
+  const bool jump = W <= 16;  // camera sets of up to 1024 slots: the parallel form (k_next / k_walk); beyond: one wave per segment (k_cut)
   int32_t *seg_nch = M.alloc<int32_t>(65), *seg_ncam = M.alloc<int32_t>(65), *cbase = M.alloc<int32_t>(66), *cambase = M.alloc<int32_t>(66);
   if (!seg_nch || !seg_ncam || !cbase || !cambase) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
   int32_t hb[2][66];
@@ -731,7 +731,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
   int32_t *tmp_cams = nullptr, *starts = nullptr;
   unsigned long long* lmask = nullptr;
   uint8_t* hvk = nullptr;
-  const int Wp = W <= 1 ? 1 : (W <= 2 ? 2 : (W <= 4 ? 4 : 8));  // the template instance
+  const int Wp = W <= 1 ? 1 : (W <= 2 ? 2 : (W <= 4 ? 4 : (W <= 8 ? 8 : 16)));  // the template instance
   if (np_chunked > 0 && jump) {
     lmask = M.alloc<unsigned long long>((size_t)np_chunked * Wp);
     int32_t* rpk = M.alloc<int32_t>((size_t)np_chunked);
@@ -748,8 +748,10 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
               hipLaunchKernelGGL(k_next<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
       case 4: hipLaunchKernelGGL(k_lm_masks<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
               hipLaunchKernelGGL(k_next<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
-      default: hipLaunchKernelGGL(k_lm_masks<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-               hipLaunchKernelGGL(k_next<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+      case 8: hipLaunchKernelGGL(k_lm_masks<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
+              hipLaunchKernelGGL(k_next<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+      default: hipLaunchKernelGGL(k_lm_masks<16>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
+               hipLaunchKernelGGL(k_next<16>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
     }
     hipLaunchKernelGGL(k_walk, dim3(1), dim3(64), 0, M.s, np_chunked, nseg, next, starts, seg_nch);
     hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(64), 0, M.s, nseg, seg_nch, seg_ncam, cbase, cambase);
@@ -787,7 +789,8 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
       case 1: hipLaunchKernelGGL(k_chunk_sets<1>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
       case 2: hipLaunchKernelGGL(k_chunk_sets<2>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
       case 4: hipLaunchKernelGGL(k_chunk_sets<4>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
-      default: hipLaunchKernelGGL(k_chunk_sets<8>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
+      case 8: hipLaunchKernelGGL(k_chunk_sets<8>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
+      default: hipLaunchKernelGGL(k_chunk_sets<16>, dim3(gc), dim3(kT), 0, M.s, nchunks, np_chunked, nseg, cbase, starts, lmask, rec_off, hvk, out.d_chunks, cncam, csets); break;
     }
     DB_TRY(hipMemsetAsync(cncam + nchunks, 0, 4, M.s));
     if ((rc = M.with_temp([&](void* t, size_t& sz) { return rocprim::exclusive_scan(t, sz, cncam, cam0, 0, (size_t)nchunks + 1, rocprim::plus<int32_t>(), M.s); }))) { (void)hipStreamSynchronize(M.s); out.release(); return rc; }
@@ -811,7 +814,8 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
       case 1: hipLaunchKernelGGL(k_chunk_cams<1>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
       case 2: hipLaunchKernelGGL(k_chunk_cams<2>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
       case 4: hipLaunchKernelGGL(k_chunk_cams<4>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
-      default: hipLaunchKernelGGL(k_chunk_cams<8>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
+      case 8: hipLaunchKernelGGL(k_chunk_cams<8>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
+      default: hipLaunchKernelGGL(k_chunk_cams<16>, dim3(gc), dim3(kT), 0, M.s, nchunks, csets, cam0, out.d_chunks, out.d_chunk_cams); break;
     }
   } else if (nchunks > 0)
     hipLaunchKernelGGL(k_chunks_final, dim3(nseg), dim3(kT), 0, M.s, np_chunked, nseg, tmp_chunks, tmp_cams, rec_off, order, info, cbase, cambase, out.d_chunks, out.d_chunk_cams);

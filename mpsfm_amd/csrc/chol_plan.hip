@@ -1,5 +1,6 @@
 // Ordering, symbolic factorisation and launch tables of the level-scheduled tile Cholesky (host code only; see chol_plan.h).
 #include "chol_plan.h"
+#include <thread>
 
 #include <algorithm>
 #include <cstdlib>
@@ -370,23 +371,39 @@ void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_ti
   int dmax = -1;
   for (int s = g.n; s >= kMinLeaf / 2; s /= 2) ++dmax;  // candidate depths down to parts of ~kMinLeaf / 2 cameras (dissect() itself
   dmax = std::min(dmax, 6);                             // stops at kMinLeaf); the cost model decides (C3: depth 3, 14 levels)
-  bool have = false;
-  std::vector<uint8_t> best_pat;
+  // the candidate orders are independent: evaluated side by side on host threads when the graph is large (C4: 6 ms one after
+  // the other), the cheapest by the launch-cost model wins, ties go to the first in this list (what the sequential loop chose)
+  struct Cand { int depth, move_up; CholPlan P; std::vector<uint8_t> pat; };
+  std::vector<Cand> cands;
   for (int d = -1; d <= (forced ? -1 : dmax); ++d) {
     const int depth = forced ? forced_depth : d;
     for (int move_up : {0, 2, 4}) {
       if (depth < 1 && move_up > 0) break;  // nothing to move without separators
-      CholPlan P;
-      P.ncv = g.n; P.nd_depth = depth;
-      P.nslots = g.n;
-      order_cameras(g, depth, move_up, P.slot_of_nat, P.col_of_slot, P.n);
-      std::vector<uint8_t> pat;
-      int nt = 0;
-      tile_pattern(g, P.slot_of_nat, P.col_of_slot, P.n, pat, nt);
-      plan_from_pattern(pat, nt, nt <= pinv_max_tiles, inv_rows, P, /*tables=*/false);
-      if (!have || P.est_us < best.est_us - 1e-9) { best = std::move(P); best_pat = std::move(pat); have = true; }
+      cands.push_back(Cand{depth, move_up, CholPlan(), {}});
     }
   }
+  auto evaluate = [&](Cand& c) {
+    CholPlan& P = c.P;
+    P.ncv = g.n; P.nd_depth = c.depth;
+    P.nslots = g.n;
+    order_cameras(g, c.depth, c.move_up, P.slot_of_nat, P.col_of_slot, P.n);
+    int nt = 0;
+    tile_pattern(g, P.slot_of_nat, P.col_of_slot, P.n, c.pat, nt);
+    plan_from_pattern(c.pat, nt, nt <= pinv_max_tiles, inv_rows, P, /*tables=*/false);
+  };
+  if (g.n >= 256 && cands.size() > 1) {
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < cands.size(); ++i) th.emplace_back([&, i] { evaluate(cands[i]); });
+    evaluate(cands[0]);
+    for (auto& x : th) x.join();
+  } else {
+    for (Cand& c : cands) evaluate(c);
+  }
+  size_t bi = 0;
+  for (size_t i = 1; i < cands.size(); ++i)
+    if (cands[i].P.est_us < cands[bi].P.est_us - 1e-9) bi = i;
+  best = std::move(cands[bi].P);
+  std::vector<uint8_t> best_pat = std::move(cands[bi].pat);
   plan_from_pattern(best_pat, best.nt, best.nt <= pinv_max_tiles, inv_rows, best, /*tables=*/true);
   best.nat_of_slot.assign((size_t)best.nslots, -1);
   for (int i = 0; i < g.n; ++i) best.nat_of_slot[(size_t)best.slot_of_nat[(size_t)i]] = i;
