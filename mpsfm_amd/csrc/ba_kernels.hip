@@ -328,11 +328,15 @@ __global__ __launch_bounds__(kThreads) void k_track_sweep(SweepArgs A) {
 // -----------------------------------------------------------------------------------------------
 // Update sweep: y_p = -(V+D)^-1 (g_p + W^T y_c), model cost change, candidate landmarks, candidate
 // cost.  Recomputes the linearisation (cheaper than storing 240 B per record in HBM).
-__global__ __launch_bounds__(kThreads, 5) void k_update_sweep(SweepArgs A) {
+#ifndef MPSFM_UPD_OCC
+#define MPSFM_UPD_OCC 4  // 102 registers without spills; LDS (12 KB) no longer limits
+#endif
+__global__ __launch_bounds__(kThreads, MPSFM_UPD_OCC) void k_update_sweep(SweepArgs A, CamUpdArgs U) {
   if (lm_over(A.ctl)) return;
   const double lm_radius = A.ctl ? lm_radius_of(A.ctl) : A.radius;
   __shared__ UpdLds S;
-  update_sweep_chunk<false>(A, blockIdx.x, lm_radius, nullptr, nullptr, A.yc, S);
+  if (U.fuse && blockIdx.x == 0) cam_update_all(U, A.yc, S.red);  // (the candidate rows of this chunk come next, like everywhere)
+  update_sweep_chunk<false>(A, blockIdx.x, lm_radius, nullptr, nullptr, A.yc, S, U, U.fuse != 0);
 }
 
 // decode q in [0, k(k+1)/2) -> (i, j), i <= j < k, row-major upper triangle
@@ -700,57 +704,8 @@ __global__ __launch_bounds__(kThreads) void k_cam_update(int nc, const int32_t* 
                                                          const LmCtl* ctl) {
   __shared__ double s_red[3 * (kThreads / 64)];
   if (lm_over(ctl)) return;
-  double step = 0.0, xn = 0.0, gmax = 0.0;
-  for (int i = threadIdx.x; i < nc; i += kThreads) {
-    const int slot = cam_slot[i];
-    double qq[4] = {q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]};
-    double tt[3] = {t[3 * i], t[3 * i + 1], t[3 * i + 2]};
-    double qn[4] = {qq[0], qq[1], qq[2], qq[3]}, tn[3] = {tt[0], tt[1], tt[2]};
-    if (slot >= 0) {
-      double dl[6], g[6];
-      for (int k = 0; k < 6; ++k) {
-        const double s = cs[6 * i + k];
-        dl[k] = s * yc[(size_t)slot * 6 + k];
-        g[k] = s > 0.0 ? -gc[(size_t)slot * 6 + k] / s : 0.0;
-      }
-      quat_plus(qq, dl, qn);
-      for (int k = 0; k < 3; ++k) tn[k] = tt[k] + dl[3 + k];
-      double qg[4];
-      quat_plus(qq, g, qg);
-      for (int k = 0; k < 4; ++k) {
-        const double d = qn[k] - qq[k];
-        step += d * d; xn += qn[k] * qn[k];
-        gmax = fmax(gmax, fabs(qg[k] - qq[k]));
-      }
-      for (int k = 0; k < 3; ++k) {
-        const double d = tn[k] - tt[k];
-        step += d * d; xn += tn[k] * tn[k];
-        gmax = fmax(gmax, fabs(g[3 + k]));
-      }
-    }
-    for (int k = 0; k < 4; ++k) q2[4 * i + k] = qn[k];
-    for (int k = 0; k < 3; ++k) t2[3 * i + k] = tn[k];
-    if (camtab2) {  // candidate camera table row (what k_build_camtab would write)
-      double* o = camtab2 + (size_t)i * kCamRec;
-      quat_to_R(qn, o);
-      o[9] = tn[0]; o[10] = tn[1]; o[11] = tn[2];
-      const double* K = intr + 4 * intr_idx[i];
-      o[12] = K[0]; o[13] = K[1]; o[14] = K[2]; o[15] = K[3];
-      for (int k = 0; k < 6; ++k) o[16 + k] = cs[6 * i + k];
-      o[22] = o[23] = 0.0;
-    }
-  }
-  step = wave_sum(step); xn = wave_sum(xn); gmax = wave_max(gmax);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { s_red[w] = step; s_red[4 + w] = xn; s_red[8 + w] = gmax; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    scal[U_STEP_SQ_CAMS] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    scal[U_XN_SQ_CAMS] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-    scal[U_GMAX_CAMS] = fmax(fmax(s_red[8], s_red[9]), fmax(s_red[10], s_red[11]));
-    // the factorisation's failure flag travels to the host with the other scalars and is re-armed here
-    if (chol_fail) { scal[U_CHOL_FAIL] = (double)*chol_fail; *chol_fail = 0; }
-  }
+  CamUpdArgs U{0, nc, cam_slot, nullptr, q, t, cs, gc, intr, intr_idx, q2, t2, camtab2, scal, chol_fail};
+  cam_update_all(U, yc, s_red);
 }
 
 // squared ambient norm of the variable landmarks (initial x_norm)
@@ -931,8 +886,10 @@ void launch_track_sweep(const SweepArgs& a, int nchunks, bool diag_only, hipStre
     else hipLaunchKernelGGL(k_long_track_sweep<MODE_FULL>, dim3(a.nlong), dim3(kThreads), 0, s, a);
   }
 }
-void launch_update_sweep(const SweepArgs& a, int nchunks, hipStream_t s) {
-  if (nchunks > 0) hipLaunchKernelGGL(k_update_sweep, dim3(nchunks), dim3(kThreads), 0, s, a);
+void launch_update_sweep(const SweepArgs& a, int nchunks, hipStream_t s, const CamUpdArgs* cu) {
+  CamUpdArgs u{};
+  if (cu) u = *cu;
+  if (nchunks > 0) hipLaunchKernelGGL(k_update_sweep, dim3(nchunks), dim3(kThreads), 0, s, a, u);
   if (a.nlong > 0) hipLaunchKernelGGL(k_long_update_sweep, dim3(a.nlong), dim3(kThreads), 0, s, a);
 }
 void launch_cost_records(const CostArgs& a, int nblocks, hipStream_t s) {

@@ -35,7 +35,7 @@ namespace mpsfm {
 // ---- declarations of the launch wrappers (ba_kernels.hip, dense_chol.hip) ------------------------
 void init_tile_tables(hipStream_t);
 void launch_track_sweep(const SweepArgs&, int nchunks, bool diag_only, hipStream_t);
-void launch_update_sweep(const SweepArgs&, int nchunks, hipStream_t);
+void launch_update_sweep(const SweepArgs&, int nchunks, hipStream_t, const CamUpdArgs* cu = nullptr);
 void launch_track_sweep_dense(const SweepArgs&, int nchunks, hipStream_t);
 void launch_reduce_slabs(const RedDest* dests, int ndest, const int32_t* srcs, const double* slab, double* Sblk, double* gc, double* wv, double* diagU,
                          const LmCtl* ctl, hipStream_t);
@@ -459,6 +459,7 @@ struct mpsfm_ba_handle {
   double* d_wl = nullptr;
   int64_t red_count = 0, sblk_count = 0, sblk_blocks = 0;
   std::vector<int32_t> perm;        // re-ordered landmark -> caller's index
+  int32_t* d_cam_of_slot = nullptr; // slot -> camera (the fused camera update of k_update_sweep)
   int32_t* d_perm = nullptr;        // device copy, and the landmarks in the caller's order as last uploaded: the state crosses the bus
   double* d_user_pts = nullptr;     // unpermuted and is re-ordered on the device (every landmark referenced: np == np_user)
   std::vector<int32_t> cam_slot_h;
@@ -515,7 +516,7 @@ static void free_handle(mpsfm_ba_handle* h) {
                   h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d,
                   h->d_fx_m, h->d_fx_a, h->d_red, h->d_part, h->d_part2, h->d_scal, h->d_costpart, h->d_A, h->d_yc, h->d_dwork, h->d_fail, h->d_lhdr, h->d_wl, h->d_slab, h->d_red_dests, h->d_red_srcs,
                   h->d_sky_first, h->d_sky_start, h->d_sky_index,
-                  h->d_local_acc, h->d_local_sync, h->d_local_log, h->d_perm, h->d_user_pts,
+                  h->d_local_acc, h->d_local_sync, h->d_local_log, h->d_perm, h->d_user_pts, h->d_cam_of_slot,
                   h->d_lp_items, h->d_lp_srcs, h->d_lp_rows, h->d_lp_struct_start, h->d_lp_struct_rows, h->d_lp_back_cols, h->d_lp_asm, h->d_lp_live, h->d_lp_col_slot};
   for (void* p : ptrs) cached_free(p);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
@@ -1652,6 +1653,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_intr_idx, intr_idx))) return rc;
   if ((rc = dev_upload(&h->d_cmask, cmask))) return rc;
   if ((rc = dev_upload(&h->d_cam_slot, h->cam_slot_h))) return rc;
+  {
+    std::vector<int32_t> cam_of_slot((size_t)std::max(h->ncv, 1), 0);
+    for (int i = 0; i < nc; ++i) if (h->cam_slot_h[(size_t)i] >= 0 && h->cam_slot_h[(size_t)i] < h->ncv) cam_of_slot[(size_t)h->cam_slot_h[(size_t)i]] = i;
+    if ((rc = dev_upload(&h->d_cam_of_slot, cam_of_slot))) return rc;
+  }
   if ((rc = dev_upload(&h->d_chunks, chunks))) return rc;
   if ((rc = dev_upload(&h->d_chunk_cams, chunk_cams))) return rc;
   if (h->np > 0 && h->np == (int64_t)h->np_user) {
@@ -2071,6 +2077,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   const LmCtl* ctl = h->d_ctl;
   const double host_radius = 0.0;  // unused: the kernels read the radius from the control block
   const bool fuse_prologue = [] { const char* e = std::getenv("MPSFM_FUSE_PROLOGUE"); return !(e && std::atoi(e) == 0); }();
+  const bool fuse_cam = [] { const char* e = std::getenv("MPSFM_FUSE_CAM"); return !(e && std::atoi(e) == 0); }();
   auto enqueue_iteration = [&](int it) -> int {
     hipEvent_t* ev = (it & 1) ? h->ev2 : h->ev;
     HIP_TRY(hipEventRecord(ev[0], s));
@@ -2083,11 +2090,16 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     HIP_TRY(hipEventRecord(ev[1], s));
     if (int rc = run_dense(h, host_radius, ctl)) return rc;
     HIP_TRY(hipEventRecord(ev[2], s));
-    launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s,
-                      h->d_intr, h->d_intr_idx, h->d_camtab2, h->d_fail, ctl);
+    // all chunks dense and one rank: the update sweep forms the candidate cameras itself (CamUpdArgs)
+    const bool fused_cam = fuse_cam && fused_prologue;
+    CamUpdArgs cu{1, h->nc, h->d_cam_slot, h->d_cam_of_slot, h->d_q, h->d_t, h->d_cs, h->d_gc, h->d_intr, h->d_intr_idx,
+                  h->d_q2, h->d_t2, h->d_camtab2, h->d_scal, h->d_fail};
+    if (!fused_cam)
+      launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s,
+                        h->d_intr, h->d_intr_idx, h->d_camtab2, h->d_fail, ctl);
     {
       SweepArgs a = sweep_args(h, host_radius, ctl);
-      launch_update_sweep(a, h->nchunks, s);
+      launch_update_sweep(a, h->nchunks, s, fused_cam ? &cu : nullptr);
     }
     if (!sharded(h)) {
       launch_lm_reduce_decide(h->d_part, h->d_part2, h->nchunks + h->nlong, h->d_ctl, h->d_scal, lo, &h->h_ctl[it & 1], s);

@@ -340,6 +340,17 @@ struct SweepArgs {
   const double* q2; const double* t2;
   double* red; int64_t nred;
 };
+// k_update_sweep with the camera update in front (all chunks dense, one rank): every workgroup forms the candidate rows of ITS chunk's
+// cameras in LDS, workgroup 0 also does what k_cam_update does for all cameras (candidate poses and table, step and state norms,
+// gradient maximum, the factorisation's failure flag) — one launch less on the iteration's critical path
+struct CamUpdArgs {
+  int32_t fuse, nc;
+  const int32_t* cam_slot;     // [nc] slot or -1
+  const int32_t* cam_of_slot;  // [ncv]
+  const double* q; const double* t; const double* cs; const double* gc;
+  const double* intr; const int32_t* intr_idx;
+  double* q2; double* t2; double* camtab2; double* scal; int* chol_fail;
+};
 __device__ inline bool lm_accepted(const LmCtl* c) { return c != nullptr && __hip_atomic_load(&c->accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 
 struct CostArgs {

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_local_lm(LocalArgs G) {
     if (writer && tid == 0) tk2 = wall_clock64();
 
     // ---- D: update sweep of the chunk; the other accumulator starts the next iteration from zero --------------------------------------
-    update_sweep_chunk<true>(A, cix, lm_radius, S.tab, S.tab2, S.y, U.upd);
+    update_sweep_chunk<true>(A, cix, lm_radius, S.tab, S.tab2, S.y, U.upd, CamUpdArgs{}, false);
     {
       double* other = G.acc[par ^ 1];
       for (int e = cix * kThreads + tid; e < kLocalAccDoubles; e += nwg * kThreads) other[e] = 0.0;

@@ -203,6 +203,87 @@ __device__ __forceinline__ const double* camera_row(const double* tab, const dou
   return tab + (size_t)cam * kCamRec;
 }
 
+// One step of the segmented scan along the lanes of a 16-lane row: adds the values of the lane SH to the left (DPP row_shr) when
+// it belongs to the same landmark.  Lanes without such a neighbour in the row receive landmark -1.
+template <int SH>
+__device__ __forceinline__ void seg_step(int my_lpt, double (&v)[9]) {
+  constexpr int ctrl = 0x110 | SH;
+  const bool same = __builtin_amdgcn_update_dpp(-1, my_lpt, ctrl, 0xf, 0xf, false) == my_lpt;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v[k]), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v[k]), ctrl, 0xf, 0xf, false);
+    v[k] += same ? __hiloint2double(hi, lo) : 0.0;
+  }
+}
+
+// Candidate pose of camera i: x [+] cs .* y (quaternion: Ceres' EigenQuaternionManifold plus), and the camera's share of the
+// step norm, the state norm and the gradient maximum (k_cam_update, the fused update sweep and local_lm.hip use the same arithmetic)
+__device__ __forceinline__ void camera_candidate(const double* qq, const double* tt, const double* cs6, const double* y6, const double* gc6, double (&qn)[4],
+                                                 double (&tn)[3], double& step, double& xn, double& gmax) {
+  double dl[6], g[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double s = cs6[k];
+    dl[k] = s * y6[k];
+    g[k] = (gc6 && s > 0.0) ? -gc6[k] / s : 0.0;
+  }
+  quat_plus(qq, dl, qn);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tn[k] = tt[k] + dl[3 + k];
+  if (gc6) {
+    double qg[4];
+    quat_plus(qq, g, qg);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double d = qn[k] - qq[k];
+      step += d * d; xn += qn[k] * qn[k];
+      gmax = fmax(gmax, fabs(qg[k] - qq[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double d = tn[k] - tt[k];
+      step += d * d; xn += tn[k] * tn[k];
+      gmax = fmax(gmax, fabs(g[3 + k]));
+    }
+  }
+}
+
+// what k_cam_update does, by one workgroup of kThreads threads; s_red: 12 doubles of LDS
+__device__ __forceinline__ void cam_update_all(const CamUpdArgs& U, const double* yc, double* s_red) {
+  double step = 0.0, xn = 0.0, gmax = 0.0;
+  for (int i = threadIdx.x; i < U.nc; i += kThreads) {
+    const int slot = U.cam_slot[i];
+    const double qq[4] = {U.q[4 * i], U.q[4 * i + 1], U.q[4 * i + 2], U.q[4 * i + 3]};
+    const double tt[3] = {U.t[3 * i], U.t[3 * i + 1], U.t[3 * i + 2]};
+    double qn[4] = {qq[0], qq[1], qq[2], qq[3]}, tn[3] = {tt[0], tt[1], tt[2]};
+    if (slot >= 0) camera_candidate(qq, tt, U.cs + 6 * i, yc + (size_t)slot * 6, U.gc + (size_t)slot * 6, qn, tn, step, xn, gmax);
+    for (int k = 0; k < 4; ++k) U.q2[4 * i + k] = qn[k];
+    for (int k = 0; k < 3; ++k) U.t2[3 * i + k] = tn[k];
+    if (U.camtab2) {  // candidate camera table row (what k_build_camtab would write)
+      double* o = U.camtab2 + (size_t)i * kCamRec;
+      quat_to_R(qn, o);
+      o[9] = tn[0]; o[10] = tn[1]; o[11] = tn[2];
+      const double* K = U.intr + 4 * U.intr_idx[i];
+      o[12] = K[0]; o[13] = K[1]; o[14] = K[2]; o[15] = K[3];
+      for (int k = 0; k < 6; ++k) o[16 + k] = U.cs[6 * i + k];
+      o[22] = o[23] = 0.0;
+    }
+  }
+  step = wave_sum(step); xn = wave_sum(xn); gmax = wave_max(gmax);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_red[w] = step; s_red[4 + w] = xn; s_red[8 + w] = gmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    U.scal[U_STEP_SQ_CAMS] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    U.scal[U_XN_SQ_CAMS] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    U.scal[U_GMAX_CAMS] = fmax(fmax(s_red[8], s_red[9]), fmax(s_red[10], s_red[11]));
+    // the factorisation's failure flag travels to the host with the other scalars and is re-armed here
+    if (U.chol_fail) { U.scal[U_CHOL_FAIL] = (double)*U.chol_fail; *U.chol_fail = 0; }
+  }
+  __syncthreads();
+}
+
 // threadIdx.x; kOpaque: behind an empty asm, so that inside a loop over LM iterations (local_lm.hip) nothing derived from it is
 // hoisted out of the loop and kept alive across every phase
 template <bool kOpaque>

@@ -12,20 +12,6 @@ constexpr int kAccG = 2 * kDenseCams * 6;
 
 }  // namespace
 
-// One step of the segmented scan along the lanes of a 16-lane row: adds the values of the lane SH to the left (DPP row_shr) when
-// it belongs to the same landmark.  Lanes without such a neighbour in the row receive landmark -1.
-template <int SH>
-__device__ __forceinline__ void seg_step(int my_lpt, double (&v)[9]) {
-  constexpr int ctrl = 0x110 | SH;
-  const bool same = __builtin_amdgcn_update_dpp(-1, my_lpt, ctrl, 0xf, 0xf, false) == my_lpt;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v[k]), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v[k]), ctrl, 0xf, 0xf, false);
-    v[k] += same ? __hiloint2double(hi, lo) : 0.0;
-  }
-}
-
 // Schur products of a chunk with at most 7 cameras (three row tiles; 4 x 28 blocks of partial sums fit the Z rows' LDS): the
 // UNITS (landmark group, coordinate) are dealt to the four waves, every wave sums all tile pairs over its units — each Z row is
 // fetched by exactly one wave, a quarter of the operand traffic of the pair-per-wave form, and the waves finish together — then

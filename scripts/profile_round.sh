@@ -31,5 +31,6 @@ python3 scripts/level_durations.py "$OUT/trace" > "$DST/${TAG}_level_durations.t
 python3 scripts/sweep_parts.py C3 C4 C5 C2 > "$DST/${TAG}_sweep_parts.txt" 2>&1
 python3 scripts/dbg_devbuild.py > "$DST/${TAG}_device_build_steps.txt" 2>&1
 python3 scripts/time_oneshot.py C3 2>&1 | grep -v "^\[mpsfm_ba\] it " > "$DST/${TAG}_one_shot.txt"
+{ python3 scripts/dbg_local.py; python3 scripts/time_local_oneshot.py 2>&1 | grep "one-shot\|create:\|build:"; } 2>&1 | grep -v amdgpu.ids > "$DST/${TAG}_local_lm.txt"
 cp "$OUT/bench_trace.json" "$DST/${TAG}_bench_under_rocprof.json"
 rm -rf "$OUT/sq_a" "$OUT/sq_b" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma" "$OUT/pmc_mfma_c4" "$OUT/trace_int"
