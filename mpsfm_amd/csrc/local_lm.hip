@@ -420,25 +420,36 @@ __global__ __launch_bounds__(kThreads, 1) void k_local_lm(LocalArgs G) {
 
     // ---- E: the iteration's scalars (k_lm_reduce_decide's order) and the decision, the same in every workgroup -----------------------
     {
-      constexpr int kWaves = kThreads / 64;
-      double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      // eight columns (0-2 track sweep: cost, invalid count, gradient maximum; 3-7 update sweep): every thread brings one row (all
+      // loads of the workgroup in flight together: they come from beyond the L2) into LDS — the phase storage is free here —, then one
+      // wave adds them, eight lanes per column, in a fixed order: cheaper than eight wave reductions
+      double* rows = reinterpret_cast<double*>(&U);
       for (int r = tid; r < G.nchunks; r += kThreads) {
         const double* a = A.part + (size_t)r * 4;
         const double* b = A.part2 + (size_t)r * 8;
-        v[0] += a[0]; v[1] += a[1]; v[2] = fmax(v[2], a[2]);
-        v[3] += b[0]; v[4] += b[1]; v[5] += b[2]; v[6] += b[3]; v[7] += b[4];
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const double w = c == 2 ? wave_max(v[c]) : wave_sum(v[c]);
-        if ((tid & 63) == 0) S.red[c * kWaves + (tid >> 6)] = w;
+        const double a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4];
+        double* o = rows + (size_t)r * 8;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = b3; o[7] = b4;
       }
       __syncthreads();
-      if (tid < 8) {
-        const double* p = &S.red[tid * kWaves];
-        double r = p[0];
-        for (int w = 1; w < kWaves; ++w) r = tid == 2 ? fmax(r, p[w]) : r + p[w];
-        S.out[tid] = r;
+      if (tid < 64) {  // lane = column + 8 * part: eight row classes per column, then three shuffle steps across the parts
+        const int c = tid & 7, part = tid >> 3;
+        const bool is_max = c == 2;
+        double p0 = 0.0, p1 = 0.0;
+        int r = part;
+        for (; r + 8 < G.nchunks; r += 16) {
+          const double x0 = rows[r * 8 + c], x1 = rows[(r + 8) * 8 + c];
+          p0 = is_max ? fmax(p0, x0) : p0 + x0;
+          p1 = is_max ? fmax(p1, x1) : p1 + x1;
+        }
+        if (r < G.nchunks) { const double x0 = rows[r * 8 + c]; p0 = is_max ? fmax(p0, x0) : p0 + x0; }
+        double v = is_max ? fmax(p0, p1) : p0 + p1;
+#pragma unroll
+        for (int off = 32; off >= 8; off >>= 1) {
+          const double o = __shfl_down(v, off, 64);
+          v = is_max ? fmax(v, o) : v + o;
+        }
+        if (tid < 8) S.out[tid] = v;
       }
       __syncthreads();
       if (tid == 0) {

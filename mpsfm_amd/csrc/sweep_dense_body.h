@@ -424,6 +424,9 @@ __device__ __forceinline__ void dense_sweep_chunk(const SweepArgs& A, int cix, d
       const int wq = ((tid >> 6) + cix) & 3;
       const int mine = npairs > wq ? (npairs - wq + 3) >> 2 : 0;  // this wave's pairs: at most 2 up to three row tiles (8 cameras), 6 beyond
       int done = 0;
+      if constexpr (kLocal) {  // one workgroup per CU there: registers for four pairs per pass (nine and more cameras: one pass instead of two)
+        for (; done + 4 <= mine; done += 4) schur_pairs<4>(S.W, S.rec, S.U, slab, tid, cix, npt, ncam, NT, ncopy, cstride, A.dbg, done);
+      }
       for (; done + 2 <= mine; done += 2) schur_pairs<2>(S.W, S.rec, S.U, slab, tid, cix, npt, ncam, NT, ncopy, cstride, A.dbg, done);
       if (done < mine) schur_pairs<1>(S.W, S.rec, S.U, slab, tid, cix, npt, ncam, NT, ncopy, cstride, A.dbg, done);
     }
