@@ -255,7 +255,7 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 // W = words of a camera set that can hold a bit (slots / 64, rounded up): lanes >= W never hold one.
 __global__ __launch_bounds__(64) void k_cut(int np_chunked, int nseg, int W, const int32_t* order, const LmInfo* info, const uint16_t* lm_slots, const int32_t* pstart,
                                             const int32_t* blk_key, const int32_t* rec_off, TmpChunk* tmp_chunks, int32_t* tmp_cams, int32_t* lm_chunk,
-                                            int32_t* seg_nchunks, int32_t* seg_ncams) {
+                                            int32_t* seg_nchunks, int32_t* seg_ncams, int rec_cap) {
   const int sidx = blockIdx.x, lane = threadIdx.x;
   const int64_t k0 = (int64_t)np_chunked * sidx / nseg, k1 = (int64_t)np_chunked * (sidx + 1) / nseg;
   extern __shared__ unsigned long long s_mask[];  // [64 landmarks of a batch][W]: their camera sets, built by one lane each
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void k_cut(int np_chunked, int nseg, int W, con
       const int nuni = subset ? -1 : set_size(cur | m);  // a subset does not grow the set (its size was admissible when it was formed)
       const bool first_of_chunk = kk == c_first;
       if (first_of_chunk) c_hv = hv;
-      const bool too_big = (c_nrec + rp > kObsMax) || (kk - c_first + 1 > (hv ? kPtsMax : kDensePts)) || (nuni > (hv ? kLocalCamsMax : kDenseCams)) || (hv != c_hv);
+      const bool too_big = (c_nrec + rp > (hv ? kObsMax : rec_cap)) || (kk - c_first + 1 > (hv ? kPtsMax : kDensePts)) || (nuni > (hv ? kLocalCamsMax : kDenseCams)) || (hv != c_hv);
       if (!first_of_chunk && too_big) {
         close_chunk(kk);
         cur = m; c_hv = hv;
@@ -364,7 +364,7 @@ __device__ __forceinline__ int seg_of(int64_t k, int np_chunked, int nseg) {
   return s;
 }
 template <int W>
-__global__ __launch_bounds__(kT) void k_next(int np_chunked, int nseg, const unsigned long long* mask, const int32_t* rp, const uint8_t* hv, int32_t* next) {
+__global__ __launch_bounds__(kT) void k_next(int np_chunked, int nseg, const unsigned long long* mask, const int32_t* rp, const uint8_t* hv, int32_t* next, int rec_cap) {
   const int k = blockIdx.x * kT + threadIdx.x;
   if (k >= np_chunked) return;
   const int64_t k1 = (int64_t)np_chunked * (seg_of(k, np_chunked, nseg) + 1) / nseg;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kT) void k_next(int np_chunked, int nseg, const uns
     for (int w = 0; w < W; ++w) { m[w] = mask[(size_t)kk * W + w]; grow = grow || (m[w] & ~cur[w]) != 0; nuni += __popcll(cur[w] | m[w]); }
     if (!grow) nuni = -1;
     const int r = rp[kk], h = hv[kk];
-    const bool too_big = (nrec + r > kObsMax) || (kk - k + 1 > (h ? kPtsMax : kDensePts)) || (nuni > (h ? kLocalCamsMax : kDenseCams)) || (h != hv0);
+    const bool too_big = (nrec + r > (h ? kObsMax : rec_cap)) || (kk - k + 1 > (h ? kPtsMax : kDensePts)) || (nuni > (h ? kLocalCamsMax : kDenseCams)) || (h != hv0);
     if (kk > k && too_big) break;
 #pragma unroll
     for (int w = 0; w < W; ++w) cur[w] |= m[w];
@@ -634,7 +634,7 @@ int DevBuilder::stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std:
   return 0;
 }
 
-int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, DevBuildOut& out) {
+int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, int rec_cap, DevBuildOut& out) {
   Impl& M = *m;
   const bool tr = std::getenv("MPSFM_DEVBUILD_TRACE") != nullptr;  // diagnostics: synchronise and print after every step
   auto t_prev = std::chrono::steady_clock::now();
@@ -743,15 +743,15 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
     DB_TRY(hipMemsetAsync(seg_ncam, 0, 4 * 65, M.s));
     switch (Wp) {
       case 1: hipLaunchKernelGGL(k_lm_masks<1>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-              hipLaunchKernelGGL(k_next<1>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+              hipLaunchKernelGGL(k_next<1>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
       case 2: hipLaunchKernelGGL(k_lm_masks<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-              hipLaunchKernelGGL(k_next<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+              hipLaunchKernelGGL(k_next<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
       case 4: hipLaunchKernelGGL(k_lm_masks<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-              hipLaunchKernelGGL(k_next<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+              hipLaunchKernelGGL(k_next<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
       case 8: hipLaunchKernelGGL(k_lm_masks<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-              hipLaunchKernelGGL(k_next<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+              hipLaunchKernelGGL(k_next<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
       default: hipLaunchKernelGGL(k_lm_masks<16>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-               hipLaunchKernelGGL(k_next<16>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next); break;
+               hipLaunchKernelGGL(k_next<16>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
     }
     hipLaunchKernelGGL(k_walk, dim3(1), dim3(64), 0, M.s, np_chunked, nseg, next, starts, seg_nch);
     hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(64), 0, M.s, nseg, seg_nch, seg_ncam, cbase, cambase);
@@ -762,7 +762,7 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, D
     tmp_cams = M.alloc<int32_t>((size_t)std::max(nrec_total, 1));
     int32_t* lm_chunk = M.alloc<int32_t>((size_t)np_chunked);
     if (!tmp_chunks || !tmp_cams || !lm_chunk) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
-    hipLaunchKernelGGL(k_cut, dim3(nseg), dim3(64), (size_t)64 * W * 8, M.s, np_chunked, nseg, W, order, info, lm_slots, M.pstart, M.blk_key, rec_off, tmp_chunks, tmp_cams, lm_chunk, seg_nch, seg_ncam);
+    hipLaunchKernelGGL(k_cut, dim3(nseg), dim3(64), (size_t)64 * W * 8, M.s, np_chunked, nseg, W, order, info, lm_slots, M.pstart, M.blk_key, rec_off, tmp_chunks, tmp_cams, lm_chunk, seg_nch, seg_ncam, rec_cap);
     hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(64), 0, M.s, nseg, seg_nch, seg_ncam, cbase, cambase);
     DB_TRY(hipMemcpyAsync(hb[0], cbase, 4 * (size_t)(nseg + 1), hipMemcpyDeviceToHost, M.s));
     DB_TRY(hipMemcpyAsync(hb[1], cambase, 4 * (size_t)(nseg + 1), hipMemcpyDeviceToHost, M.s));

@@ -35,7 +35,8 @@ class DevBuilder {
   int stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std::vector<int32_t>& nat_slot, int ncv_real, std::vector<double>& cam_counts,
              std::vector<uint64_t>& graph_bits, int graph_words, int64_t* max_blocks_per_landmark);
   // with the final camera slots: landmark order, chunk cut, record arrays.  Returns 0, MPSFM_DEVBUILD_FALLBACK or an error code.
-  int stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, DevBuildOut& out);
+  // rec_cap: records a DENSE chunk may hold (kObsMax, or less for small problems: see chunk_record_cap in ba_solver.hip)
+  int stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, int rec_cap, DevBuildOut& out);
 
  private:
   struct Impl;
