@@ -176,31 +176,33 @@ class Optimizer(BaseClass):
             todo = vp[self._track_lengths(vp) != n_in]
         else:
             todo = vp
-        extra_ids, extra_cam, extra_pt, extra_xy = [], [], [], []
         pt_of = None
-        for pid in todo:
-            pid = int(pid)
-            if pt_of is None:
+        if len(todo):
+            # their observations in images OUTSIDE the bundle, as (image id, point id, xy) in a canonical order (point, image):
+            # from the image side with bulk accessors when that is cheaper than walking every track in Python
+            out_img, out_pid, out_xy = self._outside_observations(np.asarray(todo, np.int64), in_config)
+            pos = np.searchsorted(point_ids, out_pid) if len(point_ids) else np.zeros(len(out_pid), np.int64)
+            known = (pos < len(point_ids)) & (point_ids[np.minimum(pos, max(len(point_ids) - 1, 0))] == out_pid) if len(point_ids) else np.zeros(len(out_pid), bool)
+            todo_in = np.isin(todo, point_ids) if len(point_ids) else np.zeros(len(todo), bool)
+            extra_ids = np.asarray(todo, np.int64)[~todo_in]  # explicit points no bundle image observes: appended behind the sorted ones
+            n_sorted = len(point_ids)
+            extra_pos = {int(v): n_sorted + i for i, v in enumerate(extra_ids)}
+            ept = np.where(known, pos, 0).astype(np.int64)
+            if (~known).any():
+                ept[~known] = np.fromiter((extra_pos[int(v)] for v in out_pid[~known]), np.int64, int((~known).sum()))
+            out_images = np.unique(out_img)  # outside images in ascending id order behind the bundle's
+            first_out = len(image_ids)
+            for imid in out_images:
+                cam_of[int(imid)] = len(image_ids)
+                image_ids.append(int(imid))
+            ecam = (first_out + np.searchsorted(out_images, out_img)).astype(np.int32)
+            if len(extra_ids):
+                point_ids = np.concatenate([point_ids, extra_ids])
+                num_obs = np.concatenate([num_obs, np.zeros(len(extra_ids), np.int64)])
                 pt_of = {int(v): i for i, v in enumerate(point_ids)}
-            point = rec.points3D[pid]
-            if pid not in pt_of:
-                pt_of[pid] = len(point_ids) + len(extra_ids)
-                extra_ids.append(pid)
-            for el in point.track.elements:
-                if el.image_id in in_config:
-                    continue
-                if el.image_id not in cam_of:
-                    cam_of[el.image_id] = len(image_ids)
-                    image_ids.append(el.image_id)
-                extra_cam.append(cam_of[el.image_id]); extra_pt.append(pt_of[pid])
-                extra_xy.append(np.asarray(rec.images[el.image_id].points2D[el.point2D_idx].xy, np.float64))
-        if extra_ids:
-            point_ids = np.concatenate([point_ids, np.array(extra_ids, np.int64)])
-            num_obs = np.concatenate([num_obs, np.zeros(len(extra_ids), np.int64)])
-        if extra_cam:
-            np.add.at(num_obs, np.array(extra_pt, np.int64), 1)
-            obs_cam.append(np.array(extra_cam, np.int32)); obs_pt.append(np.array(extra_pt, np.int32))
-            obs_xy.append(np.array(extra_xy, np.float64).reshape(-1, 2))
+            if len(ecam):
+                np.add.at(num_obs, ept, 1)
+                obs_cam.append(ecam); obs_pt.append(ept.astype(np.int32)); obs_xy.append(out_xy.reshape(-1, 2))
         obs_cam = np.concatenate(obs_cam) if obs_cam else np.zeros(0, np.int32)
         obs_pt = np.concatenate(obs_pt) if obs_pt else np.zeros(0, np.int32)
         obs_xy = np.concatenate(obs_xy) if obs_xy else np.zeros((0, 2))
@@ -225,7 +227,8 @@ class Optimizer(BaseClass):
 
         variable_points = []
         if mode == "local":
-            variable_points = [p for p in bundle["pts3D"] if rec.points3D[p].track.length() < 15]
+            cand = np.fromiter((int(p) for p in bundle["pts3D"]), np.int64, len(bundle["pts3D"]))
+            variable_points = cand[self._track_lengths(cand) < 15] if len(cand) else cand
         (image_ids, cam_of, point_ids, pt_of, obs_cam, obs_pt, obs_xy, pose_const, pt_const,
          gauge) = self._gather_reprojection(optim_ids, variable_points, fix_pose)
 
@@ -396,6 +399,50 @@ class Optimizer(BaseClass):
         self.truncation_multiplier = sigma
         if self.conf.min_truncation_mult is not None:
             self.truncation_multiplier = max(self.truncation_multiplier, self.conf.min_truncation_mult)
+
+    def _outside_observations(self, todo, in_config):
+        """Observations of the points `todo` in images outside `in_config`: (image ids, point ids, xy), ordered by (point, image).
+        Two ways to the same arrays: walking point.track.elements (what pycolmap's C++ bundle adjuster does for
+        config.add_variable_point, reference :88-91) costs one Python step per track element; sweeping the other images'
+        observation lists with the bulk accessors costs a few NumPy calls per image.  The cheaper one by a simple model is taken."""
+        rec = self.mpsfm_rec
+        todo_sorted = np.sort(todo)
+        others = [(imid, im) for imid, im in rec.images.items() if imid not in in_config]
+        n_elements = int(self._track_lengths(todo).sum())
+        n_cfg_obs = 0
+        for imid in list(in_config)[:4]:
+            n_cfg_obs += len(rec.images[imid].get_observation_point2D_idxs())
+        per_image = n_cfg_obs / max(min(len(in_config), 4), 1)
+        cost_tracks = 1.0 * n_elements                               # ~1 us per element visited from Python
+        cost_images = len(others) * (25.0 + 0.03 * per_image)        # ~25 us of calls + ~30 ns per observation and image
+        img_l, pid_l, xy_l = [], [], []
+        force = getattr(self, "outside_method", None)  # tests: "images" / "tracks"
+        if force == "images" or (force is None and cost_images <= cost_tracks):
+            for imid, image in others:
+                p2d = np.asarray(image.get_observation_point2D_idxs(), dtype=np.int64)
+                if len(p2d) == 0:
+                    continue
+                pids = np.asarray(image.point3D_ids(p2d), dtype=np.uint64).astype(np.int64)
+                pos = np.minimum(np.searchsorted(todo_sorted, pids), len(todo_sorted) - 1)
+                hit = todo_sorted[pos] == pids
+                if not hit.any():
+                    continue
+                img_l.append(np.full(int(hit.sum()), imid, np.int64))
+                pid_l.append(pids[hit])
+                xy_l.append(np.asarray(image.keypoint_coordinates(p2d[hit]), dtype=np.float64).reshape(-1, 2))
+        else:
+            for pid in todo:
+                els = [(el.image_id, el.point2D_idx) for el in rec.points3D[int(pid)].track.elements if el.image_id not in in_config]
+                if not els:
+                    continue
+                img_l.append(np.array([e[0] for e in els], np.int64))
+                pid_l.append(np.full(len(els), int(pid), np.int64))
+                xy_l.append(np.array([np.asarray(rec.images[i].points2D[j].xy, np.float64) for i, j in els], np.float64).reshape(-1, 2))
+        if not img_l:
+            return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 2))
+        img, pid, xy = np.concatenate(img_l), np.concatenate(pid_l), np.concatenate(xy_l)
+        order = np.lexsort((img, pid))
+        return img[order], pid[order], xy[order]
 
     def _track_lengths(self, point_ids):
         """track length of every given point: a bulk accessor when the scene has one, else the reference's per-point

@@ -99,6 +99,28 @@ def test_local_mode_pulls_outside_observations(scene):
     assert flat_g.prob.n_cams == n_cfg and flat_g.prob.pt_const.sum() > 0
 
 
+def test_outside_observations_by_tracks_and_by_images_are_the_same_arrays(scene):
+    """The local bundle's outside observations: walking every track (what pycolmap's C++ adjuster does) and sweeping the other
+    images' observation lists with the bulk accessors must assemble the same flat problem, observation for observation."""
+    sc, _, _ = scene
+    ids = sorted(sc.images.keys())
+    ref = ids[3]
+    pts = set(sc.images[ref].point3D_ids(sc.images[ref].get_observation_point2D_idxs()))
+    bundle = {"ref_id": ref, "optim_ids": {ref, ids[2], ids[4]}, "pts3D": pts, "constpoints": set()}
+    flats = []
+    for method in ("tracks", "images"):
+        opt = Optimizer({}, sc, None, backend=OracleBackend())
+        opt.outside_method = method
+        flat, _ = opt._build_problem(bundle, False, True, mode="local", solve=False)
+        flats.append(flat)
+    a, b = flats
+    assert a.prob.n_cams > 3 and a.prob.n_obs > 0
+    assert list(a.image_ids) == list(b.image_ids)
+    np.testing.assert_array_equal(a.point_ids, b.point_ids)
+    for name in ("obs_cam", "obs_pt", "obs_xy", "pose_const", "pt_const", "cam_quat", "cam_t", "pts", "dobs_cam", "dobs_pt", "dobs_depth"):
+        np.testing.assert_array_equal(getattr(a.prob, name), getattr(b.prob, name), err_msg=name)
+
+
 def test_ba_improves_poses_and_writes_back_in_place(scene):
     prob, truth = make_scene(8, 400, True, seed=21)
     sc = scene_from_problem(prob, truth, seed=3)
