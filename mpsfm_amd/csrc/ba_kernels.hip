@@ -873,6 +873,16 @@ void launch_permute_pts(int64_t np, const int32_t* perm, const double* src, doub
   hipLaunchKernelGGL(k_permute_pts, dim3((unsigned)((3 * np + 255) / 256)), dim3(256), 0, s, np, perm, src, dst, scatter ? 1 : 0);
 }
 
+// one rank: the state norm and the cost of the fixed blocks enter the control block on the device (no host round trip in front
+// of the loop): scal[U_XN_SQ_*] from k_cam_update / k_pts_sqnorm, scal[12..13] from the fixed blocks' cost reduction
+__global__ void k_lm_init(LmCtl* C, const double* scal) {
+  if (threadIdx.x == 0) {
+    C->x_norm = sqrt(scal[U_XN_SQ_PTS] + scal[U_XN_SQ_CAMS]);
+    C->fixed_cost = scal[12] + scal[13];
+  }
+}
+void launch_lm_init(LmCtl* ctl, const double* scal, hipStream_t s) { hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, s, ctl, scal); }
+
 // ---- launch wrappers ------------------------------------------------------------------------------
 void init_tile_tables(hipStream_t) {}
 

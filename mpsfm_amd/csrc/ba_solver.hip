@@ -58,6 +58,7 @@ void launch_lm_accept(const LmCtl* ctl, int nc, int64_t np, double* q, double* t
                       const double* camtab2, const double* pts2, hipStream_t);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_gmax_to_slot(double* redsc, int rank, hipStream_t);
+void launch_lm_init(LmCtl* ctl, const double* scal, hipStream_t);
 void launch_permute_pts(int64_t np, const int32_t* perm, const double* src, double* dst, bool scatter, hipStream_t);
 void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
@@ -1992,7 +1993,8 @@ static int solve_local(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   if (last.term == kLmNumericError)
     return fail(MPSFM_ENUMERIC, "the initial point cannot be evaluated (non-finite residual or depth <= 0 in a log-depth block)");
   sum->initial_cost = last.initial_cost;
-  sum->final_cost = last.cur_cost + fixed;
+  sum->fixed_cost = last.fixed_cost;  // (one rank: formed on the device)
+  sum->final_cost = last.cur_cost + last.fixed_cost;
   sum->num_iterations = last.iter;
   sum->num_successful_steps = last.n_success;
   sum->num_unsuccessful_steps = last.n_unsuccess;
@@ -2022,23 +2024,38 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     }
   }
 
-  // camera table at the initial point (unit scales) for the fixed cost
-  launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 0, h->d_cs, s);
-  launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, s);
-  double fx[3];
-  if (int rc = cost_of_records(h, h->nfixed, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d, h->d_fx_m, h->d_fx_a, fx)) return rc;
-  double fixed = fx[0] + fx[1];
-  if (int rc = allreduce_host(h, &fixed, 1)) return rc;
-  sum->fixed_cost = fixed;
-
   auto finish = [&](int rc) {
     sum->num_jacobian_evals = n_jac_evals;
     sum->num_residual_evals = (int64_t)h->nblocks_reduced_global * (n_cost_evals + n_jac_evals);
     sum->time_total_s = std::chrono::duration<double>(clk::now() - t_begin).count();
     return rc;
   };
+  // One rank: nothing in front of the loop needs the host — the cost of the fixed blocks and the state norm stay on the device
+  // and enter the control block there (k_lm_init); three stream synchronisations less per solve.  Sharded runs sum both over
+  // the ranks as host values.
+  const bool nothing_to_solve = h->n == 0 && h->nvarpts_global == 0.0;
+  const bool async_pre = !sharded(h) && !nothing_to_solve;
+  double fixed = 0.0, x_norm = 0.0;
+  // camera table at the initial point (unit scales) for the fixed cost
+  launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 0, h->d_cs, s);
+  launch_build_camtab(h->nc, h->d_q, h->d_t, h->d_intr, h->d_intr_idx, h->d_cs, h->d_camtab, s);
+  if (async_pre) {
+    HIP_TRY(hipMemsetAsync(h->d_scal, 0, sizeof(double) * U_COUNT, s));
+    if (h->nfixed > 0) {
+      const int nb = (int)std::min<int64_t>(1024, (h->nfixed + kThreads - 1) / kThreads);
+      CostArgs c{h->nfixed, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d, h->d_fx_m, h->d_fx_a, h->d_camtab, h->d_pts, h->loss, h->d_costpart};
+      launch_cost_records(c, nb, s);
+      launch_reduce_cols(h->d_costpart, nb, 4, 3, 0u, h->d_scal + 12, s);
+    }
+  } else {
+    double fx[3];
+    if (int rc = cost_of_records(h, h->nfixed, h->d_fx_cam, h->d_fx_pt, h->d_fx_meta, h->d_fx_xy, h->d_fx_d, h->d_fx_m, h->d_fx_a, fx)) return rc;
+    fixed = fx[0] + fx[1];
+    if (int rc = allreduce_host(h, &fixed, 1)) return rc;
+    sum->fixed_cost = fixed;
+  }
 
-  if (h->n == 0 && h->nvarpts_global == 0.0) {
+  if (nothing_to_solve) {
     double c3[3];
     if (int rc = cost_of_records(h, h->nrec, h->d_rec_cam, h->d_rec_pt, h->d_rec_meta, h->d_rec_xy, h->d_rec_d, h->d_rec_m, h->d_rec_a, c3)) return rc;
     double c = c3[0] + c3[1];
@@ -2052,19 +2069,20 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   if (h->np > 0) HIP_TRY(hipMemcpyAsync(h->d_pts2, h->d_pts, sizeof(double) * 3 * h->np, hipMemcpyDeviceToDevice, s));
   // initial x norm: cameras through a zero-step camera update, landmarks by a reduction
   HIP_TRY(hipMemsetAsync(h->d_yc, 0, sizeof(double) * (size_t)std::max(h->n_user, 1), s));
-  HIP_TRY(hipMemsetAsync(h->d_scal, 0, sizeof(double) * U_COUNT, s));
-  double x_norm = 0.0;
+  if (!async_pre) HIP_TRY(hipMemsetAsync(h->d_scal, 0, sizeof(double) * U_COUNT, s));
   {
     HIP_TRY(hipMemsetAsync(h->d_gc, 0, sizeof(double) * (size_t)std::max(h->n_user, 1), s));
     launch_cam_update(h->nc, h->d_cam_slot, h->d_q, h->d_t, h->d_cs, h->d_yc, h->d_gc, h->d_q2, h->d_t2, h->d_scal, s);
     const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (h->np + kThreads - 1) / kThreads));
     launch_pts_sqnorm(h->np, h->d_pt_kv, h->d_pts, h->d_costpart, nb, s);
     launch_reduce_cols(h->d_costpart, nb, 1, 1, 0u, h->d_scal + U_XN_SQ_PTS, s);
-    HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * U_COUNT, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    double v = h->h_scal[U_XN_SQ_PTS];
-    if (int rc = allreduce_host(h, &v, 1)) return rc;
-    x_norm = std::sqrt(v + h->h_scal[U_XN_SQ_CAMS]);
+    if (!async_pre) {
+      HIP_TRY(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * U_COUNT, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      double v = h->h_scal[U_XN_SQ_PTS];
+      if (int rc = allreduce_host(h, &v, 1)) return rc;
+      x_norm = std::sqrt(v + h->h_scal[U_XN_SQ_CAMS]);
+    }
   }
 
   // ---- Levenberg-Marquardt loop.  The decisions are taken on the device (k_lm_decide, LmCtl in common.h): the host
@@ -2079,7 +2097,8 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     c0.term = kLmRunning; c0.check_gradient = 1;
     h->h_ctl[0] = c0;
     HIP_TRY(hipMemcpyAsync(h->d_ctl, &h->h_ctl[0], sizeof(LmCtl), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // the pinned slot is reused below
+    if (async_pre) launch_lm_init(h->d_ctl, h->d_scal, s);  // x_norm and fixed_cost from the device scalars
+    else HIP_TRY(hipStreamSynchronize(s));  // the pinned slot is reused below
   }
   const LmOpts lo{o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.min_relative_decrease, o.max_trust_region_radius,
                   o.min_trust_region_radius, o.max_num_iterations, o.max_num_consecutive_invalid_steps};
@@ -2139,8 +2158,8 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
       last = h->h_ctl[it & 1];
       if (o.verbose > 0) {
         if (last.last_mcc > 0.0 && last.last_cand != DBL_MAX)
-          std::fprintf(stderr, "[mpsfm_ba] it %3d cost %.9e cand %.9e rel %.3e radius %.3e |step| %.3e\n", it, last.last_x_cost + fixed,
-                       last.last_cand + fixed, last.last_rel, last.radius, last.last_step_norm);
+          std::fprintf(stderr, "[mpsfm_ba] it %3d cost %.9e cand %.9e rel %.3e radius %.3e |step| %.3e\n", it, last.last_x_cost + last.fixed_cost,
+                       last.last_cand + last.fixed_cost, last.last_rel, last.radius, last.last_step_norm);
         else
           std::fprintf(stderr, "[mpsfm_ba] it %3d invalid step (chol_fail=%d mcc=%.3e) radius %.3e\n", it, last.last_chol_fail, last.last_mcc, last.radius);
       }
@@ -2157,7 +2176,8 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   if (last.term == kLmNumericError)
     return finish(fail(MPSFM_ENUMERIC, "the initial point cannot be evaluated (non-finite residual or depth <= 0 in a log-depth block)"));
   sum->initial_cost = last.initial_cost;
-  sum->final_cost = last.cur_cost + fixed;
+  sum->fixed_cost = last.fixed_cost;  // (one rank: formed on the device)
+  sum->final_cost = last.cur_cost + last.fixed_cost;
   sum->num_iterations = last.iter;
   sum->num_successful_steps = last.n_success;
   sum->num_unsuccessful_steps = last.n_unsuccess;
