@@ -115,6 +115,8 @@ def main():
         ok, cost = 1.0, 0.0
         try:
             h, collective = make_handle(True)
+            if os.environ.get("MPSFM_BENCH_INJECT_NATIVE_FAILURE"):  # tests: the fallback below must carry the run
+                raise RuntimeError("injected failure of the native RCCL path")
             cost = float(h.solve()["final_cost"])
             ok = 1.0 if np.isfinite(cost) and cost > 0.0 else 0.0
         except Exception as e:  # noqa: BLE001 - any failure of the unverified path selects the verified one

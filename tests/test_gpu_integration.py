@@ -159,7 +159,8 @@ def test_concurrent_integration_is_identical_and_faster():
         assert s1["cg_iters"] == s2["cg_iters"]
         np.testing.assert_array_equal(d1, d2)
     print(f"12 images 145x193: sequential {1e3 * t_seq:.1f} ms, 6 threads {1e3 * t_par:.1f} ms")
-    assert t_par < t_seq
+    if not os.environ.get("MPSFM_POISON"):  # (the poison fills serialise the threads' allocations: results still identical, no speed-up)
+        assert t_par < t_seq
 
 
 # ---- row f4: uncertainty propagation through the integration ---------------------------------------------

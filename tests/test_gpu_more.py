@@ -325,11 +325,12 @@ def test_max_iterations_and_tight_tolerances(speculate, monkeypatch):
         np.testing.assert_allclose(pg.pts, po.pts, rtol=0, atol=1e-8, err_msg=str(kw))
 
 
-@pytest.mark.parametrize("collective", ["rccl", "hook"])
+@pytest.mark.parametrize("collective", ["rccl", "hook", "rccl-fails"])
 def test_rccl_single_rank(collective):
     """bench.py with a one-rank NCCL(RCCL) process group.  "rccl": the library's own communicator (ncclCommInitRank from a
     unique id, ncclAllReduce on the solver's stream, no Python in the LM loop); "hook": the torch.distributed hook with
-    the zero-copy tensor view and the shared stream.  Same result as the plain single-GPU solve."""
+    the zero-copy tensor view and the shared stream; "rccl-fails": the native path's first solve is made to fail, the run
+    must continue on the hook by itself.  Same result as the plain single-GPU solve."""
     import json
     import os
     import subprocess
@@ -337,7 +338,9 @@ def test_rccl_single_rank(collective):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MPSFM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               MPSFM_BENCH_COLLECTIVE=collective)
+               MPSFM_BENCH_COLLECTIVE="hook" if collective == "hook" else "rccl")
+    if collective == "rccl-fails":
+        env["MPSFM_BENCH_INJECT_NATIVE_FAILURE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C2", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--kernel-reps", "2"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -347,6 +350,8 @@ def test_rccl_single_rank(collective):
     assert d["solve"]["final_cost"] == pytest.approx(s["final_cost"], rel=1e-9)
     assert d["solve"]["lm_iterations"] == s["num_iterations"]
     assert ("native RCCL" if collective == "rccl" else "hook") in d["config"]["parallelism"]
+    if collective == "rccl-fails":
+        assert "falling back" in r.stderr
 
 
 @pytest.mark.timeout(600)
