@@ -249,6 +249,9 @@ static int dev_alloc(T** p, size_t count) {
 // Uploads of caller / table memory go through a process-wide pinned staging buffer (two halves, the host copy
 // into one overlaps the DMA out of the other).  Handing pageable memory to hipMemcpy directly makes the
 // runtime pin and later unpin every source range: measured 17 ms of stall after a 40 MB table upload.
+// pageable -> pinned copy of one staging half: a single thread's memcpy (~20 GB/s here) is what bounded the uploads, not the bus;
+// a few host threads in parallel (defined behind run_parts)
+static void staged_copy(char* dst, const char* src, size_t n);
 struct Stager {
   static constexpr size_t kHalf = (size_t)8 << 20;
   std::mutex mu;
@@ -283,7 +286,7 @@ struct Stager {
       const int hf = next;
       next ^= 1;
       if (busy[hf]) { HIP_TRY(hipEventSynchronize(ev[hf])); busy[hf] = false; }
-      std::memcpy(buf + (size_t)hf * kHalf, s, n);
+      staged_copy(buf + (size_t)hf * kHalf, s, n);
       HIP_TRY(hipMemcpyAsync(d, buf + (size_t)hf * kHalf, n, hipMemcpyHostToDevice, st));
       HIP_TRY(hipEventRecord(ev[hf], st));
       busy[hf] = true;
@@ -716,6 +719,17 @@ static void parallel_ranges(int64_t n, int64_t min_grain, F&& f) {
   const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / std::max<int64_t>(min_grain, 1)));
   if (parts <= 1) { f((int64_t)0, n); return; }
   run_parts(parts, [&](int t, int np) { f(n * t / np, n * (t + 1) / np); });
+}
+
+static void staged_copy(char* dst, const char* src, size_t n) {
+  constexpr size_t kGrain = (size_t)1 << 20;
+  static const int max_threads = [] { const char* e = std::getenv("MPSFM_STAGE_THREADS"); return e ? std::max(std::atoi(e), 1) : 6; }();
+  const int parts = (int)std::min<size_t>((size_t)std::min(host_threads(), max_threads), n / kGrain);
+  if (parts <= 1) { std::memcpy(dst, src, n); return; }
+  run_parts(parts, [&](int t, int np) {
+    const size_t a = (n * (size_t)t / (size_t)np) & ~(size_t)63, b = t + 1 == np ? n : ((n * (size_t)(t + 1) / (size_t)np) & ~(size_t)63);
+    std::memcpy(dst + a, src + a, b - a);
+  });
 }
 
 // Build the re-ordered, chunked record tables and upload everything.
