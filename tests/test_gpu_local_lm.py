@@ -134,6 +134,10 @@ def test_problems_the_single_launch_leaves_to_the_chain(monkeypatch):
     with capi.BAHandle(make_scene(18, 3000, True, seed=1)[0]) as h:
         h.solve()
         assert local_iterations(h) == -1
+    # more chunks than workgroups the device keeps resident at once (one per CU)
+    with capi.BAHandle(make_scene(10, 20000, True, seed=1)[0]) as h:
+        h.solve()
+        assert local_iterations(h) == -1
     # a landmark with a track beyond a chunk's camera list: general chunks
     monkeypatch.setenv("MPSFM_SWEEP_DENSE", "0")
     with capi.BAHandle(make_scene(8, 1000, True, seed=1)[0]) as h:
