@@ -1051,7 +1051,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     if (const char* e = std::getenv("MPSFM_CHOL_ND")) forced_depth = std::atoi(e);  // -1: caller's order, >= 0: dissection depth
     int inv_rows = 2;
     if (const char* e = std::getenv("MPSFM_CHOL_INVERSE")) if (std::atoi(e) == 0) inv_rows = -1;
-    plan_auto(graph, forced_depth, forced_depth >= -1, inv_rows < 0 ? 0 : dense_plain_max_tiles(), dense_inv_rows(), h->plan);
+    plan_auto(graph, forced_depth, forced_depth >= -1, inv_rows < 0 ? 0 : dense_plain_max_tiles(), dense_inv_rows(), h->plan,
+              [](int n, void (*fn)(void*, int), void* ctx) { run_parts(n, [&](int t, int) { fn(ctx, t); }); });
     lap("camera order + factorisation plan");
     h->nat_slot = h->plan.slot_of_nat;
     h->ncv = h->plan.nslots;                 // a permutation of the variable cameras
@@ -1604,7 +1605,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   // -- slabs of the dense chunks and the tables of their reduction (k_reduce_slabs): per destination — a block of S or a camera's
   //    vectors — the slab positions that contribute, in chunk order; destinations with many sources are split into parts
   std::vector<RedDest> red_dests;
-  std::vector<int32_t> red_srcs;
+  std::vector<int32_t> red_srcs, diag_block;
+  bool slab_tables_on_device = false;
   int64_t slab_units = 0;
   {
     h->n_dense = 0;
@@ -1618,12 +1620,20 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       h->n_dense = (int)c + 1;
     }
     const int64_t nsb = h->sblk_blocks;
+    // a device-built handle forms the tables on the device too (DevBuilder::slab_tables, behind the uploads below)
+    slab_tables_on_device = dev && devb && h->n_dense > 0 && !(std::getenv("MPSFM_SLAB_TABLES_HOST") && std::atoi(std::getenv("MPSFM_SLAB_TABLES_HOST")) != 0);
     auto host_sky = [&](int si, int sj) -> int64_t {
       return use_graph ? (int64_t)h->sky_index[(size_t)sj * (size_t)h->ncv + (size_t)si] : h->sky_start[(size_t)sj] + (si - h->sky_first[(size_t)sj]);
     };
     const size_t ndst = (size_t)nsb + (size_t)std::max(h->ncv, 0);
+    diag_block.assign((size_t)std::max(h->ncv, 1), -1);
+    for (int sl = 0; sl < h->ncv; ++sl) {
+      if (use_graph && h->plan.nat_of_slot[(size_t)sl] < 0) continue;
+      const int64_t b = host_sky(sl, sl);
+      if (b >= 0 && b < nsb) diag_block[(size_t)sl] = (int32_t)b;
+    }
     std::vector<int32_t> cnt(ndst + 1, 0);
-    for (int pass = 0; pass < 2; ++pass) {  // count, then place (chunk order within a destination)
+    for (int pass = 0; pass < 2 && !slab_tables_on_device; ++pass) {  // count, then place (chunk order within a destination)
       if (pass == 1) {
         for (size_t d = 1; d <= ndst; ++d) cnt[d] += cnt[d - 1];
         red_srcs.resize((size_t)cnt[ndst]);
@@ -1654,7 +1664,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
       if (b >= 0 && b < nsb) is_diag[(size_t)b] = 1;
     }
     constexpr int kPart = 16;
-    for (size_t d = 0; d < ndst; ++d) {
+    for (size_t d = 0; d < ndst && !slab_tables_on_device; ++d) {
       const int32_t s0 = d == 0 ? 0 : cnt[d - 1], s1 = cnt[d];
       for (int32_t q = s0; q < s1; q += kPart) {
         RedDest R;
@@ -1721,11 +1731,23 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   if ((rc = dev_upload(&h->d_blk_desc, blk_desc))) return rc;
   if ((rc = dev_upload(&h->d_blk_ent_start, blk_ent_start))) return rc;
   if ((rc = dev_upload(&h->d_ents, ents))) return rc;
-  if ((rc = dev_upload(&h->d_red_dests, red_dests))) return rc;
-  if ((rc = dev_upload(&h->d_red_srcs, red_srcs))) return rc;
+  int32_t* d_diag_block = nullptr;
+  if (!slab_tables_on_device) {
+    if ((rc = dev_upload(&h->d_red_dests, red_dests))) return rc;
+    if ((rc = dev_upload(&h->d_red_srcs, red_srcs))) return rc;
+  } else if ((rc = dev_upload(&d_diag_block, diag_block))) return rc;
   if ((rc = dev_alloc(&h->d_slab, (size_t)std::max<int64_t>(slab_units, 1) * 18))) return rc;
 
-  if ((rc = drain_uploads())) return rc;
+  if ((rc = drain_uploads())) { cached_free(d_diag_block); return rc; }
+  if (slab_tables_on_device) {
+    const BlockSky sky{h->d_sky_first, h->d_sky_start, h->d_sky_index, h->ncv};
+    int32_t nd = 0; int64_t ns = 0;
+    rc = devb->slab_tables(h->d_chunks, h->n_dense, h->d_chunk_cams, sky, h->sblk_blocks, h->ncv, d_diag_block, &h->d_red_dests, &nd, &h->d_red_srcs, &ns);
+    HIP_TRY(hipStreamSynchronize(h->stream));  // d_diag_block goes back to the process-wide cache
+    cached_free(d_diag_block);
+    if (rc) return rc;
+    h->n_red_dests = nd; h->n_red_srcs = ns;
+  }
   lap("upload tables");
   const size_t ncs = (size_t)std::max(nc, 1), nps = (size_t)std::max<int64_t>(h->np, 1);
   for (double** p : {&h->d_q, &h->d_q2, &h->d_q0}) if ((rc = dev_alloc(p, ncs * 4))) return rc;

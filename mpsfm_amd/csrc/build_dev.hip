@@ -533,6 +533,71 @@ __global__ __launch_bounds__(kT) void k_records(int n_order, int np_chunked, int
   if ((threadIdx.x & 63) == 0) { if (sb) atomicAdd(&counters[0], sb); if (sv) atomicAdd(&counters[1], (unsigned long long)sv); }
 }
 
+
+// ---- reduction tables of the dense chunks' slabs (k_reduce_slabs) -------------------------------------------------------------
+// one entry per (chunk, block of S it contributes to) and per (chunk, camera): key = destination (block index, or nsb + slot),
+// value = position of the source in the slabs (units of 18 doubles).  A stable sort by destination keeps chunk order inside a
+// destination — the fixed summation order of k_reduce_slabs — exactly as the host's counting sort does.
+__global__ __launch_bounds__(kT) void k_slab_entry_counts(int n_dense, const ChunkHdr* chunks, int32_t* nent) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c > n_dense) return;
+  nent[c] = c < n_dense ? chunks[c].ncam * (chunks[c].ncam + 1) / 2 + chunks[c].ncam : 0;
+}
+__global__ __launch_bounds__(64) void k_slab_entries(int n_dense, const ChunkHdr* chunks, const int32_t* chunk_cams, BlockSky sky, int64_t nsb, int ndst,
+                                                     const int32_t* ent0, uint32_t* key, int32_t* val, int32_t* cnt, int32_t* err) {
+  const int c = blockIdx.x;
+  if (c >= n_dense) return;
+  const ChunkHdr H = chunks[c];
+  const int32_t* cams = chunk_cams + H.cam0;
+  const int nb = H.ncam * (H.ncam + 1) / 2;
+  for (int e = threadIdx.x; e < nb + H.ncam; e += 64) {
+    uint32_t k;
+    int32_t v;
+    if (e < nb) {
+      int cj = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while (cj * (cj + 1) / 2 > e) --cj;
+      while ((cj + 1) * (cj + 2) / 2 <= e) ++cj;
+      const int ci = e - cj * (cj + 1) / 2;
+      const int lo = cams[ci], hi = cams[cj];
+      int64_t b;
+      if (sky.index) b = sky.index[(int64_t)hi * sky.ns + lo];
+      else b = sky.start[hi] + (lo - sky.first[hi]);
+      if (b >= nsb) { atomicOr(&err[1], 1); b = -1; }
+      k = b < 0 ? (uint32_t)ndst : (uint32_t)b;  // two cameras of the chunk that share no landmark anywhere: S has no such block
+      v = H.slab0 + 2 * e;
+    } else {
+      k = (uint32_t)(nsb + cams[e - nb]);
+      v = H.slab0 + 2 * nb + (e - nb);
+    }
+    key[ent0[c] + e] = k;
+    val[ent0[c] + e] = v;
+    if (k < (uint32_t)ndst) atomicAdd(&cnt[k], 1);
+  }
+}
+__global__ __launch_bounds__(kT) void k_slab_mark_diag(int ncv, const int32_t* diag_block, int64_t nsb, uint8_t* is_diag) {
+  const int sl = blockIdx.x * kT + threadIdx.x;
+  if (sl >= ncv) return;
+  const int32_t b = diag_block[sl];
+  if (b >= 0 && b < nsb) is_diag[b] = 1;
+}
+__global__ __launch_bounds__(kT) void k_slab_part_counts(int ndst, const int32_t* cnt, int32_t* nparts) {
+  const int d = blockIdx.x * kT + threadIdx.x;
+  if (d > ndst) return;
+  nparts[d] = d < ndst ? (cnt[d] + 15) / 16 : 0;
+}
+__global__ __launch_bounds__(kT) void k_slab_parts(int ndst, int64_t nsb, const int32_t* cnt, const int32_t* start, const int32_t* pstart, const uint8_t* is_diag,
+                                                   RedDest* out) {
+  const int d = blockIdx.x * kT + threadIdx.x;
+  if (d >= ndst) return;
+  const int n = cnt[d], s0 = start[d];
+  RedDest R;
+  R.kind = d >= nsb ? 2 : (is_diag[d] ? 1 : 0);
+  R.dst = d >= nsb ? (int32_t)(d - nsb) : d;
+  for (int q = 0, o = pstart[d]; q < n; q += 16, ++o) {
+    R.s0 = s0 + q; R.s1 = s0 + min(q + 16, n);
+    out[o] = R;
+  }
+}
 }  // namespace
 
 struct DevBuilder::Impl {
@@ -843,6 +908,58 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, i
   lap("downloads");
   if (er[0] & 2) { out.release(); return dfail(MPSFM_EINVAL, "shifted/scaled depth prior must be positive"); }
   out.nblk_reduced = (int64_t)hc[0]; out.nvarpts = (double)hc[1];
+  return 0;
+}
+
+// Reduction tables of the dense chunks' slabs from the device copies of the chunk headers (slab offsets set) and camera lists.
+int DevBuilder::slab_tables(const ChunkHdr* d_chunks, int n_dense, const int32_t* d_chunk_cams, const BlockSky& sky, int64_t nsb, int ncv,
+                            const int32_t* d_diag_block, RedDest** d_dests, int32_t* n_dests, int32_t** d_srcs, int64_t* n_srcs) {
+  Impl& M = *m;
+  *d_dests = nullptr; *d_srcs = nullptr; *n_dests = 0; *n_srcs = 0;
+  if (n_dense <= 0) return 0;
+  const int ndst = (int)(nsb + ncv);
+  int rc = 0;
+  int32_t* nent = M.alloc<int32_t>((size_t)n_dense + 1);
+  int32_t* ent0 = M.alloc<int32_t>((size_t)n_dense + 1);
+  int32_t* cnt = M.alloc<int32_t>((size_t)ndst + 1);
+  int32_t* start = M.alloc<int32_t>((size_t)ndst + 1);
+  int32_t* nparts = M.alloc<int32_t>((size_t)ndst + 1);
+  int32_t* pstart = M.alloc<int32_t>((size_t)ndst + 1);
+  uint8_t* is_diag = M.alloc<uint8_t>((size_t)std::max<int64_t>(nsb, 1));
+  if (!nent || !ent0 || !cnt || !start || !nparts || !pstart || !is_diag) return dfail(MPSFM_ENOMEM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_slab_entry_counts, dim3((unsigned)((n_dense + 1 + kT - 1) / kT)), dim3(kT), 0, M.s, n_dense, d_chunks, nent);
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, nent, ent0, 0, (size_t)n_dense + 1, rocprim::plus<int32_t>(), M.s); }))) return rc;
+  int32_t n_ent = 0;
+  DB_TRY(hipMemcpyAsync(&n_ent, ent0 + n_dense, 4, hipMemcpyDeviceToHost, M.s));
+  DB_TRY(hipMemsetAsync(cnt, 0, 4 * ((size_t)ndst + 1), M.s));
+  DB_TRY(hipMemsetAsync(is_diag, 0, (size_t)std::max<int64_t>(nsb, 1), M.s));
+  DB_TRY(hipMemsetAsync(M.err, 0, 16, M.s));
+  DB_TRY(hipStreamSynchronize(M.s));
+  if (n_ent <= 0) return 0;
+  uint32_t* key = M.alloc<uint32_t>((size_t)n_ent);
+  uint32_t* key_s = M.alloc<uint32_t>((size_t)n_ent);
+  int32_t* val = M.alloc<int32_t>((size_t)n_ent);
+  int32_t* val_s = (int32_t*)cached_malloc(4 * (size_t)n_ent);  // becomes the source list: owned by the caller
+  if (!key || !key_s || !val || !val_s) { cached_free(val_s); return dfail(MPSFM_ENOMEM, "hipMalloc failed"); }
+  auto bail = [&](int code) { (void)hipStreamSynchronize(M.s); cached_free(val_s); return code; };
+  hipLaunchKernelGGL(k_slab_entries, dim3((unsigned)n_dense), dim3(64), 0, M.s, n_dense, d_chunks, d_chunk_cams, sky, nsb, ndst, ent0, key, val, cnt, M.err);
+  hipLaunchKernelGGL(k_slab_mark_diag, dim3((unsigned)((ncv + kT - 1) / kT)), dim3(kT), 0, M.s, ncv, d_diag_block, nsb, is_diag);
+  unsigned bits = 1;
+  while ((1u << bits) <= (unsigned)ndst) ++bits;  // keys 0 .. ndst (ndst: no destination)
+  if ((rc = M.with_temp([&](void* t, size_t& sz) { return rocprim::radix_sort_pairs(t, sz, key, key_s, val, val_s, (size_t)n_ent, 0, bits, M.s); }))) return bail(rc);
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, cnt, start, 0, (size_t)ndst + 1, rocprim::plus<int32_t>(), M.s); }))) return bail(rc);
+  hipLaunchKernelGGL(k_slab_part_counts, dim3((unsigned)((ndst + 1 + kT - 1) / kT)), dim3(kT), 0, M.s, ndst, cnt, nparts);
+  if ((rc = M.with_temp([&](void* t, size_t& b) { return rocprim::exclusive_scan(t, b, nparts, pstart, 0, (size_t)ndst + 1, rocprim::plus<int32_t>(), M.s); }))) return bail(rc);
+  int32_t tot[2] = {0, 0}, er[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(&tot[0], start + ndst, 4, hipMemcpyDeviceToHost, M.s) != hipSuccess || hipMemcpyAsync(&tot[1], pstart + ndst, 4, hipMemcpyDeviceToHost, M.s) != hipSuccess ||
+      hipMemcpyAsync(er, M.err, 16, hipMemcpyDeviceToHost, M.s) != hipSuccess || hipStreamSynchronize(M.s) != hipSuccess)
+    return bail(dfail(MPSFM_EHIP, "device build: copying the slab table sizes failed"));
+  if (er[1]) return bail(dfail(MPSFM_EUNSUPPORTED, "internal: block index beyond S"));
+  RedDest* dests = (RedDest*)cached_malloc(sizeof(RedDest) * (size_t)std::max(tot[1], 1));
+  if (!dests) return bail(dfail(MPSFM_ENOMEM, "hipMalloc failed"));
+  hipLaunchKernelGGL(k_slab_parts, dim3((unsigned)((ndst + kT - 1) / kT)), dim3(kT), 0, M.s, ndst, nsb, cnt, start, pstart, is_diag, dests);
+  if (hipGetLastError() != hipSuccess) { cached_free(dests); return bail(dfail(MPSFM_EHIP, "device build: slab table kernels failed")); }
+  *d_dests = dests; *n_dests = tot[1]; *d_srcs = val_s; *n_srcs = tot[0];
   return 0;
 }
 

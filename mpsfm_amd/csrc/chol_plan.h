@@ -63,6 +63,8 @@ void order_cameras(const CamGraph& g, int depth, int move_up, std::vector<int32_
 void tile_pattern(const CamGraph& g, const std::vector<int32_t>& slot_of_nat, const std::vector<int32_t>& col_of_slot, int n_cols,
                   std::vector<uint8_t>& pat, int& nt);
 // tries the caller's order and dissection depths 0 .. max, keeps the cheapest by the launch-cost model (forced_depth >= -1: that one)
-void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_tiles, int inv_rows, CholPlan& P);
+// pfor(n, fn, ctx): runs fn(ctx, i) for i in [0, n), possibly on several threads (the caller's worker pool); NULL: one after the other
+typedef void (*PlanParallelFor)(int n, void (*fn)(void* ctx, int i), void* ctx);
+void plan_auto(const CamGraph& g, int forced_depth, bool forced, int pinv_max_tiles, int inv_rows, CholPlan& P, PlanParallelFor pfor = nullptr);
 
 }  // namespace mpsfm

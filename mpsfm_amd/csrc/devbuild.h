@@ -37,6 +37,11 @@ class DevBuilder {
   // with the final camera slots: landmark order, chunk cut, record arrays.  Returns 0, MPSFM_DEVBUILD_FALLBACK or an error code.
   // rec_cap: records a DENSE chunk may hold (kObsMax, or less for small problems: see chunk_record_cap in ba_solver.hip)
   int stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, int rec_cap, DevBuildOut& out);
+  // the reduction tables of the dense chunks' slabs (k_reduce_slabs) from device copies of the chunk headers (slab offsets set) and
+  // camera lists; d_diag_block[slot]: the block of S on that slot's diagonal or -1.  The two tables are the receiver's
+  // (cached_malloc blocks); stage1 must have run (the builder's stream).
+  int slab_tables(const ChunkHdr* d_chunks, int n_dense, const int32_t* d_chunk_cams, const BlockSky& sky, int64_t nsb, int ncv, const int32_t* d_diag_block,
+                  RedDest** d_dests, int32_t* n_dests, int32_t** d_srcs, int64_t* n_srcs);
 
  private:
   struct Impl;
