@@ -1621,7 +1621,11 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
     }
     const int64_t nsb = h->sblk_blocks;
     // a device-built handle forms the tables on the device too (DevBuilder::slab_tables, behind the uploads below)
-    slab_tables_on_device = dev && devb && h->n_dense > 0 && !(std::getenv("MPSFM_SLAB_TABLES_HOST") && std::atoi(std::getenv("MPSFM_SLAB_TABLES_HOST")) != 0);
+    {
+      const char* e = std::getenv("MPSFM_SLAB_TABLES_HOST");  // 1: host loop, 0: device kernels (tests), unset: by size — below ~500
+      const int pref = e ? std::atoi(e) : -1;                  // chunks the host loop is quicker than the launches
+      slab_tables_on_device = dev && devb && h->n_dense > 0 && (pref == 0 || (pref < 0 && h->n_dense >= 512));
+    }
     auto host_sky = [&](int si, int sj) -> int64_t {
       return use_graph ? (int64_t)h->sky_index[(size_t)sj * (size_t)h->ncv + (size_t)si] : h->sky_start[(size_t)sj] + (si - h->sky_first[(size_t)sj]);
     };

@@ -42,10 +42,12 @@ def both(prob, monkeypatch):
         hh.reset_state()
         sh = hh.solve()
     monkeypatch.delenv("MPSFM_DEV_BUILD")
+    monkeypatch.setenv("MPSFM_SLAB_TABLES_HOST", "0")  # the slab reduction tables from the device kernels whatever the size
     with capi.BAHandle(prob.copy()) as hd:
         td = tables(hd)
         hd.reset_state()
         sd = hd.solve()
+    monkeypatch.delenv("MPSFM_SLAB_TABLES_HOST")
     return th, td, sh, sd
 
 
