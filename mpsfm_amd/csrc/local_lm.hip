@@ -368,31 +368,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_local_lm(LocalArgs G) {
     // ---- B: the reduced system, every workgroup for itself ------------------------------------------------------------------------------
     local_dense_solve(S, U.dense, acc, n, lm_radius, A.min_diag, A.max_diag, (writer && tid == 0 && (A.dbg & 64)) ? G.clk : nullptr);
 
-    // ---- C: candidate cameras (k_cam_update's arithmetic), one thread per variable camera ---------------------------------------------
+    // ---- C: candidate cameras (camera_candidate: k_cam_update's arithmetic), one thread per variable camera ---------------------------------------------
     if (tid < ncv) {
-      const int sl = tid, i = S.cam_of_slot[sl];
+      const int sl = tid;
       const double qq[4] = {S.q[4 * sl], S.q[4 * sl + 1], S.q[4 * sl + 2], S.q[4 * sl + 3]};
       const double tt[3] = {S.t[3 * sl], S.t[3 * sl + 1], S.t[3 * sl + 2]};
-      double dl[6], g[6], qn[4], tn[3], qg[4];
-      for (int k = 0; k < 6; ++k) {
-        const double s = S.cs[6 * sl + k];
-        dl[k] = s * S.y[6 * sl + k];
-        g[k] = s > 0.0 ? -S.gcv[6 * sl + k] / s : 0.0;
-      }
-      quat_plus(qq, dl, qn);
-      for (int k = 0; k < 3; ++k) tn[k] = tt[k] + dl[3 + k];
-      quat_plus(qq, g, qg);
-      double step = 0.0, xn = 0.0, gmax = 0.0;
-      for (int k = 0; k < 4; ++k) {
-        const double d = qn[k] - qq[k];
-        step += d * d; xn += qn[k] * qn[k];
-        gmax = fmax(gmax, fabs(qg[k] - qq[k]));
-      }
-      for (int k = 0; k < 3; ++k) {
-        const double d = tn[k] - tt[k];
-        step += d * d; xn += tn[k] * tn[k];
-        gmax = fmax(gmax, fabs(g[3 + k]));
-      }
+      double qn[4], tn[3], step = 0.0, xn = 0.0, gmax = 0.0;
+      camera_candidate(qq, tt, &S.cs[6 * sl], &S.y[6 * sl], &S.gcv[6 * sl], qn, tn, step, xn, gmax);
       S.camred[3 * sl] = step; S.camred[3 * sl + 1] = xn; S.camred[3 * sl + 2] = gmax;
       for (int k = 0; k < 4; ++k) S.q2[4 * sl + k] = qn[k];
       for (int k = 0; k < 3; ++k) S.t2[3 * sl + k] = tn[k];
@@ -400,7 +382,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_local_lm(LocalArgs G) {
       quat_to_R(qn, o);
       o[9] = tn[0]; o[10] = tn[1]; o[11] = tn[2];
       for (int k = 12; k < kCamRec; ++k) o[k] = S.tab[sl * kCamRec + k];  // intrinsics, column scales, padding
-      (void)i;
     }
     __syncthreads();
     long long tk2 = 0;
