@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+# The CPU oracle is OpenMP code.  On a shared host (the GPU boxes show 256 CPUs and load averages of 50+) 256 spinning threads turn
+# a 2 s solve into minutes: a bounded team that sleeps at its barriers, unless the caller says otherwise.  Set before libgomp loads.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
