@@ -121,6 +121,7 @@ class HipIncrementalTriangulator:
             setattr(self, k, v)
         g = CTriGraph(len(self.image_ids), self.kp_start.ctypes.data, self.kp_xy.ctypes.data, self.intr.ctypes.data,
                       self.corr_start.ctypes.data, self.corr_kp.ctypes.data)
+        self._image_ids_arr = np.asarray(self.image_ids)
         self._h = C.c_void_p(None)
         L.mpsfm_triangulator_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
         capi._check(L.mpsfm_triangulator_create(C.byref(g), device, C.byref(self._h)))
@@ -158,7 +159,7 @@ class HipIncrementalTriangulator:
         cst = CTriState(st["registered"].ctypes.data, st["cam_quat_xyzw"].ctypes.data, st["cam_t"].ctypes.data, st["kp_point"].ctypes.data,
                         len(self._point_ids), st["xyz"].ctypes.data)
         capi._check(capi.lib().mpsfm_triangulator_set_state(self._h, C.byref(cst)))
-        self._scene_id = {i: int(p) for i, p in enumerate(self._point_ids)}  # engine point -> scene point id
+        self._scene_id = dict(enumerate(self._point_ids.tolist()))  # engine point -> scene point id
 
     def _track_types(self):
         rec = self.rec
@@ -183,23 +184,38 @@ class HipIncrementalTriangulator:
             capi._check(L.mpsfm_triangulator_get_op_elements(self._h, els.ctypes.data))
         Track, TrackElement = self._track_types()
         obs, sid = self.rec.obs, self._scene_id
+        # plain Python ints for the loop below (NumPy scalars cost ~10 x as much per use): the (image id, keypoint index) of every
+        # element of the added points and of every added observation, the op fields
+        ids_arr = self._image_ids_arr
+        el_im = self.kp_image[els] if len(els) else np.zeros(0, np.int64)
+        el_image = ids_arr[el_im].tolist()
+        el_idx = (els - self.kp_start[el_im]).tolist()
+        is_obs = typ == 1
+        ob_im = self.kp_image[np.where(is_obs, b, 0)]
+        ob_image = ids_arr[ob_im].tolist()
+        ob_idx = np.where(is_obs, b - self.kp_start[ob_im], 0).tolist()
+        typ_l, a_l, b_l = typ.tolist(), a.tolist(), b.tolist()
         e0 = 0
         modified = set()
         for k in range(n):
-            if typ[k] == 0:  # add point
+            tk, ak = typ_l[k], a_l[k]
+            if tk == 0:  # add point
                 tr = Track()
-                for kp in els[e0:e0 + b[k]]:
-                    tr.add_element(*self._element(int(kp)))
-                e0 += int(b[k])
-                sid[int(a[k])] = int(obs.add_point3D(xyz[k].copy(), tr))
-                modified.add(sid[int(a[k])])
-            elif typ[k] == 1:  # add observation
-                image_id, idx = self._element(int(b[k]))
-                obs.add_observation(sid[int(a[k])], TrackElement(image_id, idx))
-                modified.add(sid[int(a[k])])
+                e1 = e0 + b_l[k]
+                for j in range(e0, e1):
+                    tr.add_element(el_image[j], el_idx[j])
+                e0 = e1
+                pid = int(obs.add_point3D(xyz[k].copy(), tr))
+                sid[ak] = pid
+                modified.add(pid)
+            elif tk == 1:  # add observation
+                pid = sid[ak]
+                obs.add_observation(pid, TrackElement(ob_image[k], ob_idx[k]))
+                modified.add(pid)
             else:  # delete point
-                obs.delete_point3D(sid[int(a[k])])
-                modified.discard(sid[int(a[k])])
+                pid = sid[ak]
+                obs.delete_point3D(pid)
+                modified.discard(pid)
         self.last_ops = dict(type=typ, a=a, b=b, xyz=xyz, elements=els)
         self.modified_point3D_ids = modified
         return n
