@@ -2149,8 +2149,9 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
   auto enqueue_iteration = [&](int it) -> int {
     hipEvent_t* ev = (it & 1) ? h->ev2 : h->ev;
     HIP_TRY(hipEventRecord(ev[0], s));
-    // all chunks dense and one rank: the dense sweep adopts an accepted candidate and zeroes the reduced buffer itself
-    const bool fused_prologue = fuse_prologue && !sharded(h) && h->nlong == 0 && h->n_dense > 0 && h->n_dense == h->nchunks;
+    // all chunks dense: the dense sweep adopts an accepted candidate and zeroes the reduced buffer itself (sharded runs too: the
+    // exchange of the reduced buffer comes behind the slab reduction, the camera scalars are the same on every rank)
+    const bool fused_prologue = fuse_prologue && h->nlong == 0 && h->n_dense > 0 && h->n_dense == h->nchunks;
     if (!fused_prologue)
       launch_lm_prologue(h->d_ctl, h->d_red, h->red_count, h->nc, h->np, h->d_q, h->d_t, h->d_camtab, h->d_pts, h->d_q2, h->d_t2, h->d_camtab2, h->d_pts2, s);
     if (int rc = run_track_sweep(h, host_radius, ctl, true, fused_prologue)) return rc;

@@ -333,14 +333,14 @@ struct SweepArgs {
   double* pts2;            // candidate landmarks
   double* part2;           // [nchunks][8]
   const LmCtl* ctl;        // inside a solve: trust-region radius and the stop flag live on the device (NULL: `radius` above)
-  // k_track_sweep_dense as the first launch of an iteration (all chunks dense, one rank): what k_lm_prologue would do — an accepted
+  // k_track_sweep_dense as the first launch of an iteration (all chunks dense): what k_lm_prologue would do — an accepted
   // candidate becomes the state, the reduced buffer starts from zero — is spread over the sweep's workgroups
   int32_t adopt_on, adopt_nc;
   double* pts_rw; double* q_rw; double* t_rw; double* camtab_rw;
   const double* q2; const double* t2;
   double* red; int64_t nred;
 };
-// k_update_sweep with the camera update in front (all chunks dense, one rank): every workgroup forms the candidate rows of ITS chunk's
+// k_update_sweep with the camera update in front (all chunks dense): every workgroup forms the candidate rows of ITS chunk's
 // cameras in LDS, workgroup 0 also does what k_cam_update does for all cameras (candidate poses and table, step and state norms,
 // gradient maximum, the factorisation's failure flag) — one launch less on the iteration's critical path
 struct CamUpdArgs {
