@@ -873,15 +873,22 @@ void launch_permute_pts(int64_t np, const int32_t* perm, const double* src, doub
   hipLaunchKernelGGL(k_permute_pts, dim3((unsigned)((3 * np + 255) / 256)), dim3(256), 0, s, np, perm, src, dst, scatter ? 1 : 0);
 }
 
-// one rank: the state norm and the cost of the fixed blocks enter the control block on the device (no host round trip in front
-// of the loop): scal[U_XN_SQ_*] from k_cam_update / k_pts_sqnorm, scal[12..13] from the fixed blocks' cost reduction
-__global__ void k_lm_init(LmCtl* C, const double* scal) {
+// The state norm and the cost of the fixed blocks enter the control block on the device (no host round trip in front of the
+// loop): scal[U_XN_SQ_*] from k_cam_update / k_pts_sqnorm, scal[12..13] from the fixed blocks' cost reduction.  Sharded runs:
+// k_lm_pack puts the three values that are sums over the ranks' landmarks into one small buffer, the exchange sums it, k_lm_init
+// reads it back (the camera part of the norm is the same on every rank and stays out).
+__global__ void k_lm_pack(const double* scal, double* sums) {
+  if (threadIdx.x == 0) { sums[0] = scal[12]; sums[1] = scal[13]; sums[2] = scal[U_XN_SQ_PTS]; }
+}
+__global__ void k_lm_init(LmCtl* C, const double* scal, const double* sums) {
   if (threadIdx.x == 0) {
-    C->x_norm = sqrt(scal[U_XN_SQ_PTS] + scal[U_XN_SQ_CAMS]);
-    C->fixed_cost = scal[12] + scal[13];
+    const double f0 = sums ? sums[0] : scal[12], f1 = sums ? sums[1] : scal[13], xp = sums ? sums[2] : scal[U_XN_SQ_PTS];
+    C->x_norm = sqrt(xp + scal[U_XN_SQ_CAMS]);
+    C->fixed_cost = f0 + f1;
   }
 }
-void launch_lm_init(LmCtl* ctl, const double* scal, hipStream_t s) { hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, s, ctl, scal); }
+void launch_lm_pack(const double* scal, double* sums, hipStream_t s) { hipLaunchKernelGGL(k_lm_pack, dim3(1), dim3(64), 0, s, scal, sums); }
+void launch_lm_init(LmCtl* ctl, const double* scal, const double* sums, hipStream_t s) { hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, s, ctl, scal, sums); }
 
 // ---- launch wrappers ------------------------------------------------------------------------------
 void init_tile_tables(hipStream_t) {}

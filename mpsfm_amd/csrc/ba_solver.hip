@@ -58,7 +58,8 @@ void launch_lm_accept(const LmCtl* ctl, int nc, int64_t np, double* q, double* t
                       const double* camtab2, const double* pts2, hipStream_t);
 void launch_pts_sqnorm(int64_t np, const uint16_t* pt_kv, const double* pts, double* part, int nblocks, hipStream_t);
 void launch_gmax_to_slot(double* redsc, int rank, hipStream_t);
-void launch_lm_init(LmCtl* ctl, const double* scal, hipStream_t);
+void launch_lm_pack(const double* scal, double* sums, hipStream_t);
+void launch_lm_init(LmCtl* ctl, const double* scal, const double* sums, hipStream_t);
 void launch_permute_pts(int64_t np, const int32_t* perm, const double* src, double* dst, bool scatter, hipStream_t);
 void launch_gmax_from_slots(const double* redsc, double* scal, hipStream_t);
 void launch_assemble(const AssembleArgs&, hipStream_t);
@@ -2070,11 +2071,11 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     sum->time_total_s = std::chrono::duration<double>(clk::now() - t_begin).count();
     return rc;
   };
-  // One rank: nothing in front of the loop needs the host — the cost of the fixed blocks and the state norm stay on the device
-  // and enter the control block there (k_lm_init); three stream synchronisations less per solve.  Sharded runs sum both over
-  // the ranks as host values.
+  // Nothing in front of the loop needs the host — the cost of the fixed blocks and the state norm stay on the device and enter
+  // the control block there (k_lm_init); three stream synchronisations less per solve.  Sharded runs sum them over the ranks
+  // in one small exchange on the device.
   const bool nothing_to_solve = h->n == 0 && h->nvarpts_global == 0.0;
-  const bool async_pre = !sharded(h) && !nothing_to_solve;
+  const bool async_pre = !nothing_to_solve;
   double fixed = 0.0, x_norm = 0.0;
   // camera table at the initial point (unit scales) for the fixed cost
   launch_cam_scales(h->nc, h->d_cam_slot, h->d_cmask, h->d_diagU, 0, h->d_cs, s);
@@ -2137,7 +2138,15 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
     c0.term = kLmRunning; c0.check_gradient = 1;
     h->h_ctl[0] = c0;
     HIP_TRY(hipMemcpyAsync(h->d_ctl, &h->h_ctl[0], sizeof(LmCtl), hipMemcpyHostToDevice, s));
-    if (async_pre) launch_lm_init(h->d_ctl, h->d_scal, s);  // x_norm and fixed_cost from the device scalars
+    if (async_pre) {  // x_norm and fixed_cost from the device scalars
+      double* sums = nullptr;
+      if (sharded(h)) {
+        sums = h->d_costpart;  // (free again: its reductions are queued in front)
+        launch_lm_pack(h->d_scal, sums, s);
+        if (int rc = allreduce_dev(h, sums, 3)) return rc;
+      }
+      launch_lm_init(h->d_ctl, h->d_scal, sums, s);
+    }
     else HIP_TRY(hipStreamSynchronize(s));  // the pinned slot is reused below
   }
   const LmOpts lo{o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.min_relative_decrease, o.max_trust_region_radius,

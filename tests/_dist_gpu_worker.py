@@ -34,6 +34,9 @@ def main():
     res = {"supported": supported}
     if supported:
         prob, _ = make_scene(12, 6000, True, seed=int(sys.argv[2]))
+        if os.environ.get("MPSFM_TEST_FIXED"):  # constant cameras x constant landmarks: fixed blocks, whose cost is a sum over the ranks
+            prob.pose_const[2:5] = 1
+            prob.pt_const[::4] = 1
         shard, (lo, hi) = shard_problem(prob, rank, world)
         fn, keep = make_torch_allreduce()
         opts = capi.default_options(device=0, verbose=int(os.environ.get("MPSFM_VERBOSE", "0")))  # stream 0: the library creates its own, the hook must follow it

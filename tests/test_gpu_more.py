@@ -355,14 +355,16 @@ def test_rccl_single_rank(collective):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("gtol", [None, 5.0e3])
+@pytest.mark.parametrize("gtol", [None, 5.0e3, "fixed"])
 def test_two_process_sharded_solve_on_one_gpu(tmp_path, gtol):
     """Two OS processes, one landmark shard each, both on cuda:0; the reduced system is summed across them on
     the DEVICE buffers through mpsfm_amd.dist.make_torch_allreduce (gloo here: RCCL does not allow two ranks
     on one GPU).  The library runs on a stream of its own, so this fails if the hook does not order the
     collective with that stream.  Must reproduce the single-process trajectory — also when the solve ends on the
     gradient tolerance (gtol case): the landmark-gradient maximum is a MAX over ranks inside a SUM all-reduce (per-rank
-    slots), a sum of the per-rank maxima would stop later than the single-process solve."""
+    slots), a sum of the per-rank maxima would stop later than the single-process solve.  "fixed": constant cameras and
+    landmarks give fixed blocks, whose cost (and the landmark part of the state norm) is summed over the ranks on the device
+    in front of the loop."""
     import json
     import os
     import socket
@@ -370,6 +372,9 @@ def test_two_process_sharded_solve_on_one_gpu(tmp_path, gtol):
     import sys
 
     seed, world = 77, 2
+    fixed = gtol == "fixed"
+    if fixed:
+        gtol = None
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -377,7 +382,7 @@ def test_two_process_sharded_solve_on_one_gpu(tmp_path, gtol):
     procs = []
     for r in range(world):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), OMP_NUM_THREADS="2",
-                   MPSFM_TEST_GTOL="" if gtol is None else repr(gtol))
+                   MPSFM_TEST_GTOL="" if gtol is None else repr(gtol), MPSFM_TEST_FIXED="1" if fixed else "")
         procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), str(seed)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
@@ -387,7 +392,12 @@ def test_two_process_sharded_solve_on_one_gpu(tmp_path, gtol):
     if not all(r["supported"] for r in res):
         pytest.skip("this torch build cannot all-reduce device tensors with gloo")
     ref, _ = make_scene(12, 6000, True, seed=seed)
+    if fixed:
+        ref.pose_const[2:5] = 1
+        ref.pt_const[::4] = 1
     s = capi.ba_solve(ref, capi.default_options(**({} if gtol is None else {"gradient_tolerance": gtol})))
+    if fixed:
+        assert s["fixed_cost"] > 0.0
     assert s["termination"] == ("function_tolerance" if gtol is None else "gradient_tolerance")
     if gtol is not None:
         assert 2 <= s["num_iterations"] < 12
