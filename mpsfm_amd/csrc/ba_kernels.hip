@@ -656,10 +656,13 @@ __device__ __forceinline__ void reduce_cols_block(const double* part, int64_t ro
   }
   __syncthreads();
 }
+// gmax_slot >= 0 (sharded runs, the track sweep's scalars): the landmark-gradient maximum moves into this rank's slot of the
+// tail behind the sums (k_gmax_to_slot's job: a MAX inside a SUM all-reduce)
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_cols(const double* part, int64_t rows, int stride, int ncols,
-                                                                uint32_t max_mask, double* out, double* out2) {
+                                                                uint32_t max_mask, double* out, double* out2, int gmax_slot) {
   __shared__ double s[8 * (kReduceThreads / 64)];
   reduce_cols_block(part, rows, stride, ncols, max_mask, out, out2, s);
+  if (gmax_slot >= 0 && threadIdx.x == 0) { out[SC_RANK0 + gmax_slot] = out[SC_GMAX_PTS]; out[SC_GMAX_PTS] = 0.0; }
 }
 
 // ---- camera-side kernels ------------------------------------------------------------------------
@@ -755,8 +758,16 @@ __device__ __forceinline__ void lm_copy_to_host(const LmCtl* C, LmCtl* host_copy
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // no fence: the end of the kernel releases at system scope, and the host only looks after the event behind it
 }
-__global__ __launch_bounds__(64) void k_lm_decide(LmCtl* C, const double* sc, LmOpts o, LmCtl* host_copy) {
+// redsc != NULL (sharded runs): the all-reduced scalars of the track sweep enter first — cost and invalid count summed, the
+// landmark-gradient maximum over the rank slots (k_gmax_from_slots' job)
+__global__ __launch_bounds__(64) void k_lm_decide(LmCtl* C, double* sc, LmOpts o, LmCtl* host_copy, const double* redsc) {
   const bool live = C->term == kLmRunning;
+  if (live && threadIdx.x == 0 && redsc) {
+    double m = 0.0;
+    for (int r = 0; r < kMaxRankSlots; ++r) m = fmax(m, redsc[SC_RANK0 + r]);
+    sc[U_X_COST] = redsc[SC_COST]; sc[U_X_BAD] = redsc[SC_BAD]; sc[U_GMAX_PTS] = m;
+    __threadfence();  // lm_decide_thread reads the scalars past the L1
+  }
   if (live && threadIdx.x == 0) lm_decide_thread(C, sc, o);
   __syncthreads();  // one workgroup: the barrier's workgroup-scope release / acquire orders thread 0's stores before the copy
   // the host's copy of the block goes straight into its pinned slot (device-visible host memory): no copy command in the loop
@@ -913,8 +924,8 @@ void launch_cost_records(const CostArgs& a, int nblocks, hipStream_t s) {
   hipLaunchKernelGGL(k_cost_records, dim3(nblocks), dim3(kThreads), 0, s, a);
 }
 void launch_reduce_cols(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out,
-                        hipStream_t s, double* out2) {
-  hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(kReduceThreads), 0, s, part, rows, stride, ncols, max_mask, out, out2);
+                        hipStream_t s, double* out2, int gmax_slot) {
+  hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(kReduceThreads), 0, s, part, rows, stride, ncols, max_mask, out, out2, gmax_slot);
 }
 void launch_build_camtab(int nc, const double* q, const double* t, const double* intr, const int32_t* intr_idx,
                          const double* cs, double* camtab, hipStream_t s) {
@@ -937,8 +948,8 @@ void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const d
   hipLaunchKernelGGL(k_cam_update, dim3(1), dim3(kThreads), 0, s, nc, cam_slot, q, t, cs, yc, gc, q2, t2, scal, intr, intr_idx,
                      camtab2, chol_fail, ctl);
 }
-void launch_lm_decide(LmCtl* ctl, const double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t s) {
-  hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(64), 0, s, ctl, scal, o, host_copy);
+void launch_lm_decide(LmCtl* ctl, double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t s, const double* redsc) {
+  hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(64), 0, s, ctl, scal, o, host_copy, redsc);
 }
 __global__ __launch_bounds__(256) void k_zero(double* p, int64_t n, const LmCtl* ctl) {
   if (lm_over(ctl)) return;

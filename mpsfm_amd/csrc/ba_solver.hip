@@ -41,7 +41,7 @@ void launch_reduce_slabs(const RedDest* dests, int ndest, const int32_t* srcs, c
                          const LmCtl* ctl, hipStream_t);
 void launch_cost_records(const CostArgs&, int nblocks, hipStream_t);
 void launch_reduce_cols(const double* part, int64_t rows, int stride, int ncols, uint32_t max_mask, double* out, hipStream_t,
-                        double* out2 = nullptr);
+                        double* out2 = nullptr, int gmax_slot = -1);
 void launch_build_camtab(int nc, const double* q, const double* t, const double* intr, const int32_t* intr_idx,
                          const double* cs, double* camtab, hipStream_t);
 void launch_cam_scales(int nc, const int32_t* cam_slot, const double* cmask, const double* diagU, int jacobi, double* cs, hipStream_t);
@@ -49,7 +49,7 @@ void launch_pt_scales(int64_t np, const uint16_t* pt_kv, const double* diagV, in
 void launch_cam_update(int nc, const int32_t* cam_slot, const double* q, const double* t, const double* cs, const double* yc,
                        const double* gc, double* q2, double* t2, double* scal, hipStream_t, const double* intr = nullptr,
                        const int32_t* intr_idx = nullptr, double* camtab2 = nullptr, int* chol_fail = nullptr, const LmCtl* ctl = nullptr);
-void launch_lm_decide(LmCtl* ctl, const double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t);
+void launch_lm_decide(LmCtl* ctl, double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t, const double* redsc = nullptr);
 void launch_zero(double* p, int64_t n, const LmCtl* ctl, hipStream_t);
 void launch_lm_reduce_decide(const double* part, const double* part2, int64_t rows, LmCtl* ctl, double* scal, const LmOpts& o, LmCtl* host_copy, hipStream_t);
 void launch_lm_prologue(const LmCtl* ctl, double* red, int64_t nred, int nc, int64_t np, double* q, double* t, double* camtab, double* pts, const double* q2,
@@ -1938,8 +1938,9 @@ static int run_track_sweep(mpsfm_ba_handle* h, double radius, const LmCtl* ctl =
   }
   launch_sweeps(h, a, s);
   if (h->nchunks + h->nlong > 0 && !(in_loop && !sharded(h)))
-    launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, sharded(h) ? nullptr : h->d_scal + U_X_COST);
-  if (sharded(h)) launch_gmax_to_slot(h->d_redsc, h->opt.rank > 0 ? h->opt.rank : 0, s);
+    launch_reduce_cols(h->d_part, h->nchunks + h->nlong, 4, 3, 1u << 2, h->d_redsc, s, sharded(h) ? nullptr : h->d_scal + U_X_COST,
+                       sharded(h) ? (h->opt.rank > 0 ? h->opt.rank : 0) % kMaxRankSlots : -1);
+  else if (sharded(h)) launch_gmax_to_slot(h->d_redsc, h->opt.rank > 0 ? h->opt.rank : 0, s);  // (a rank without chunks: its slot from the zeroed buffer)
   h->last_radius = radius;
   return 0;
 }
@@ -2185,8 +2186,7 @@ static int solve_impl(mpsfm_ba_handle* h, mpsfm_ba_summary* sum) {
       if (h->nchunks + h->nlong > 0) launch_reduce_cols(h->d_part2, h->nchunks + h->nlong, 8, 5, 0u, h->d_scal, s);
       if (int rc = allreduce_dev(h, h->d_scal, 5)) return rc;
       // the all-reduced scalars of the track sweep: cost and bad count summed, landmark-gradient maximum over the rank slots
-      launch_gmax_from_slots(h->d_redsc, h->d_scal, s);
-      launch_lm_decide(h->d_ctl, h->d_scal, lo, &h->h_ctl[it & 1], s);
+      launch_lm_decide(h->d_ctl, h->d_scal, lo, &h->h_ctl[it & 1], s, h->d_redsc);
     }
     HIP_TRY(hipEventRecord(ev[3], s));
     return 0;
