@@ -51,8 +51,7 @@ struct LocalState {
   double cs[kLocalCams * 6];
   double y[kLocalN], z[kLocalN], rhs[kLocalN], gcv[kLocalN], v2[kLocalN], v[kTile], vp[8 * kTile];
   double camred[kLocalCams * 3];
-  double sc[U_COUNT];
-  double red[8 * (kThreads / 64)], out[8];
+  double red[kThreads / 64], out[8];
   int32_t cam_of_slot[kLocalCams];
   int16_t rc[kPer3Decl * kThreads];   // gather_system's element list
   int32_t flag, fail, epoch, pad_;

@@ -6,7 +6,7 @@
 
 namespace mpsfm {
 
-// LDS of one chunk's update sweep (10.3 KB)
+// LDS of one chunk's update sweep (12 KB)
 struct UpdLds {
   double V[kPtsMax * 6];
   double g[kPtsMax * 3];   // g_p + W^T y_c
