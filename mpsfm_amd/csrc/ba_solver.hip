@@ -936,6 +936,8 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   // cut into ~40 smaller ones: every sweep costs ONE workgroup's latency, which grows with the chunk's landmarks — measured in the
   // single launch of local_lm.hip: 3 cameras / 300 landmarks 39 -> 34 us per iteration with 24 chunks instead of 6; beyond ~40
   // chunks its grid barriers (~35 ns per workgroup each) take back what the sweep gains.  MPSFM_CHUNK_RECORDS overrides.
+  // landmarks of a dense chunk by the size of its camera set (dense_pts_cap): small problems, MPSFM_CHUNK_PTS_BY_CAMS overrides
+  const int pts_by_cams = [&] { const char* e = std::getenv("MPSFM_CHUNK_PTS_BY_CAMS"); return e ? (std::atoi(e) != 0 ? 1 : 0) : ((!sharded(h) && h->ncv >= 1 && h->ncv <= kLocalCams) ? 1 : 0); }();
   int rec_cap = kObsMax;
   constexpr int64_t kSmallChunks = 40;
   if (const char* e = std::getenv("MPSFM_CHUNK_RECORDS")) rec_cap = std::min(std::max(std::atoi(e), 16), (int)kObsMax);
@@ -1084,7 +1086,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
   std::vector<int32_t> fx_cam, fx_pt; std::vector<uint32_t> fx_meta; std::vector<double> fx_xy, fx_d, fx_m, fx_a;
   if (dev) {
     const bool dense_on = !(std::getenv("MPSFM_SWEEP_DENSE") && std::atoi(std::getenv("MPSFM_SWEEP_DENSE")) == 0);
-    const int rc2 = devb->stage2(slot, dense_on, rec_cap, DB);
+    const int rc2 = devb->stage2(slot, dense_on, rec_cap, pts_by_cams, DB);
     if (rc2 < 0) return rc2;
     if (rc2 == MPSFM_DEVBUILD_FALLBACK) {
       // long tracks: the host phases run after all — Phase A first, which was skipped
@@ -1359,7 +1361,7 @@ static int build(mpsfm_ba_handle* h, const mpsfm_ba_problem* P, const mpsfm_ba_s
             nuni = uni.size();
           }
           const bool hv = heavy_flag[(size_t)p] != 0;
-          const bool too_big = (c_nrec + r_p > (hv ? kObsMax : rec_cap)) || (k - c_first + 1 > (hv ? kPtsMax : kDensePts)) || ((int)nuni > (hv ? kLocalCamsMax : kDenseCams)) ||
+          const bool too_big = (c_nrec + r_p > (hv ? kObsMax : rec_cap)) || (k - c_first + 1 > (hv ? kPtsMax : dense_pts_cap((int)nuni, pts_by_cams))) || ((int)nuni > (hv ? kLocalCamsMax : kDenseCams)) ||
                                (hv != (heavy_flag[(size_t)order[(size_t)c_first]] != 0));  // dense and general landmarks never share a chunk
           if (k > c_first && too_big) {
             close_chunk(k);

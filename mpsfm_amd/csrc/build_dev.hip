@@ -364,7 +364,7 @@ __device__ __forceinline__ int seg_of(int64_t k, int np_chunked, int nseg) {
   return s;
 }
 template <int W>
-__global__ __launch_bounds__(kT) void k_next(int np_chunked, int nseg, const unsigned long long* mask, const int32_t* rp, const uint8_t* hv, int32_t* next, int rec_cap) {
+__global__ __launch_bounds__(kT) void k_next(int np_chunked, int nseg, const unsigned long long* mask, const int32_t* rp, const uint8_t* hv, int32_t* next, int rec_cap, int pts_by_cams) {
   const int k = blockIdx.x * kT + threadIdx.x;
   if (k >= np_chunked) return;
   const int64_t k1 = (int64_t)np_chunked * (seg_of(k, np_chunked, nseg) + 1) / nseg;
@@ -380,9 +380,10 @@ __global__ __launch_bounds__(kT) void k_next(int np_chunked, int nseg, const uns
     int nuni = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) { m[w] = mask[(size_t)kk * W + w]; grow = grow || (m[w] & ~cur[w]) != 0; nuni += __popcll(cur[w] | m[w]); }
+    const int nset = nuni;  // the chunk's camera set with this landmark
     if (!grow) nuni = -1;
     const int r = rp[kk], h = hv[kk];
-    const bool too_big = (nrec + r > (h ? kObsMax : rec_cap)) || (kk - k + 1 > (h ? kPtsMax : kDensePts)) || (nuni > (h ? kLocalCamsMax : kDenseCams)) || (h != hv0);
+    const bool too_big = (nrec + r > (h ? kObsMax : rec_cap)) || (kk - k + 1 > (h ? kPtsMax : dense_pts_cap(nset, pts_by_cams))) || (nuni > (h ? kLocalCamsMax : kDenseCams)) || (h != hv0);
     if (kk > k && too_big) break;
 #pragma unroll
     for (int w = 0; w < W; ++w) cur[w] |= m[w];
@@ -699,7 +700,7 @@ int DevBuilder::stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std:
   return 0;
 }
 
-int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, int rec_cap, DevBuildOut& out) {
+int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, int rec_cap, int pts_by_cams, DevBuildOut& out) {
   Impl& M = *m;
   const bool tr = std::getenv("MPSFM_DEVBUILD_TRACE") != nullptr;  // diagnostics: synchronise and print after every step
   auto t_prev = std::chrono::steady_clock::now();
@@ -808,15 +809,15 @@ int DevBuilder::stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, i
     DB_TRY(hipMemsetAsync(seg_ncam, 0, 4 * 65, M.s));
     switch (Wp) {
       case 1: hipLaunchKernelGGL(k_lm_masks<1>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-              hipLaunchKernelGGL(k_next<1>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
+              hipLaunchKernelGGL(k_next<1>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap, pts_by_cams); break;
       case 2: hipLaunchKernelGGL(k_lm_masks<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-              hipLaunchKernelGGL(k_next<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
+              hipLaunchKernelGGL(k_next<2>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap, pts_by_cams); break;
       case 4: hipLaunchKernelGGL(k_lm_masks<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-              hipLaunchKernelGGL(k_next<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
+              hipLaunchKernelGGL(k_next<4>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap, pts_by_cams); break;
       case 8: hipLaunchKernelGGL(k_lm_masks<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-              hipLaunchKernelGGL(k_next<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
+              hipLaunchKernelGGL(k_next<8>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap, pts_by_cams); break;
       default: hipLaunchKernelGGL(k_lm_masks<16>, dim3(gk), dim3(kT), 0, M.s, np_chunked, order, info, lm_slots, M.pstart, M.blk_key, lmask, rpk, hvk);
-               hipLaunchKernelGGL(k_next<16>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap); break;
+               hipLaunchKernelGGL(k_next<16>, dim3(gk), dim3(kT), 0, M.s, np_chunked, nseg, lmask, rpk, hvk, next, rec_cap, pts_by_cams); break;
     }
     hipLaunchKernelGGL(k_walk, dim3(1), dim3(64), 0, M.s, np_chunked, nseg, next, starts, seg_nch);
     hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(64), 0, M.s, nseg, seg_nch, seg_ncam, cbase, cambase);

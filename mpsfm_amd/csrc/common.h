@@ -63,6 +63,9 @@ struct ChunkHdr {
 };
 constexpr int kDenseCams = 16;  // 16 cameras x 6 rows = 96 rows = six 16-row MFMA tiles
 constexpr int kDensePts = 96;   // landmarks of a dense chunk
+// ... by the size of its camera set when `by_cams` (small problems: one workgroup per chunk and CU, the slowest chunk sets the pace and
+// a chunk's Schur products grow with landmarks x tile pairs): 96 up to 6 cameras, 64 up to 8, 48 up to 12, 32 beyond
+__host__ __device__ inline int dense_pts_cap(int ncams, int by_cams) { return (!by_cams || ncams <= 6) ? kDensePts : (ncams <= 8 ? 64 : (ncams <= 12 ? 48 : 32)); }
 // slab of a dense chunk: [ncam (ncam + 1) / 2 blocks (ci <= cj at cj (cj + 1) / 2 + ci) x 36][ncam x (g_c 6 | W V^-1 g_p 6 | diag U 6)] doubles,
 // written with plain stores by k_track_sweep_dense and summed per destination by k_reduce_slabs
 __host__ __device__ inline int64_t slab_doubles(int ncam) { return (int64_t)(ncam * (ncam + 1) / 2) * 36 + (int64_t)ncam * 18; }

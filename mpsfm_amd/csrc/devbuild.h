@@ -35,8 +35,8 @@ class DevBuilder {
   int stage1(const mpsfm_ba_problem* P, hipStream_t stream, const std::vector<int32_t>& nat_slot, int ncv_real, std::vector<double>& cam_counts,
              std::vector<uint64_t>& graph_bits, int graph_words, int64_t* max_blocks_per_landmark);
   // with the final camera slots: landmark order, chunk cut, record arrays.  Returns 0, MPSFM_DEVBUILD_FALLBACK or an error code.
-  // rec_cap: records a DENSE chunk may hold (kObsMax, or less for small problems: see chunk_record_cap in ba_solver.hip)
-  int stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, int rec_cap, DevBuildOut& out);
+  // rec_cap: records a DENSE chunk may hold (kObsMax, or less for small problems); pts_by_cams: dense_pts_cap by the camera set (build())
+  int stage2(const std::vector<int32_t>& slot_of_cam, bool dense_on, int rec_cap, int pts_by_cams, DevBuildOut& out);
   // the reduction tables of the dense chunks' slabs (k_reduce_slabs) from device copies of the chunk headers (slab offsets set) and
   // camera lists; d_diag_block[slot]: the block of S on that slot's diagonal or -1.  The two tables are the receiver's
   // (cached_malloc blocks); stage1 must have run (the builder's stream).
