@@ -171,3 +171,39 @@ def test_concurrent_single_launch_solves():
     for i in range(len(probs)):
         for r in range(3):
             assert got[i][r] == pytest.approx(want[i], rel=1e-11)
+
+
+def _small_random_problem(seed):
+    rng = np.random.default_rng(5000 + seed)
+    n_cams = int(rng.integers(2, 20))
+    n_pts = int(rng.integers(20, 6000))
+    prob, _ = make_scene(n_cams, n_pts, bool(rng.integers(0, 2)), seed=seed, outlier_frac=float(rng.choice([0.0, 0.05, 0.2])),
+                         max_track=int(rng.choice([3, 8, 20])))
+    if rng.random() < 0.5:
+        prob.pt_const[rng.random(prob.n_pts) < 0.15] = 1
+    if rng.random() < 0.5 and n_cams > 3:
+        prob.pose_const[rng.choice(np.arange(1, n_cams), size=max(1, n_cams // 4), replace=False)] = 1
+    if rng.random() < 0.3:
+        prob.reproj_loss_type = int(rng.integers(0, 3))
+    return prob
+
+
+@pytest.mark.timeout(600)
+def test_random_small_problems_against_the_oracle():
+    """Shapes around the single launch's limits (2-19 cameras, 20-6000 landmarks, constant cameras and landmarks, every loss): what
+    scripts/fuzz_local.py runs over hundreds of seeds, thirty of them here.  Most take the single launch; all must agree with the oracle."""
+    n_local = 0
+    for seed in range(30):
+        pg, po = _small_random_problem(seed), _small_random_problem(seed)
+        try:
+            so = O.solve(po)
+        except Exception:  # noqa: BLE001 - a scene the oracle rejects (no variable block): not this test's subject
+            continue
+        with capi.BAHandle(pg) as h:
+            sg = h.solve()
+            n_local += int(local_iterations(h) >= 0)
+        assert sg["termination"] == so["termination"], seed
+        assert abs(sg["num_iterations"] - so["num_iterations"]) <= 1, seed  # a tolerance test may fall either side by rounding
+        assert sg["initial_cost"] == pytest.approx(so["initial_cost"], rel=1e-11), seed
+        assert sg["final_cost"] == pytest.approx(so["final_cost"], rel=1e-6), seed
+    assert n_local >= 20
