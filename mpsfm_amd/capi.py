@@ -114,6 +114,31 @@ def make_allreduce(fn):
     return ALLREDUCE_FN(_cb)
 
 
+# Handles still open when the interpreter exits are closed from a Python atexit hook, i.e. BEFORE the C runtime's own exit
+# handlers: a handle destroyed later (garbage collection at shutdown, static destruction) calls into a HIP runtime that may already
+# be gone — under rocprofv3, whose tool finalisation runs first, that was a segmentation fault at exit.
+_open_handles: "weakref.WeakSet" = None
+
+
+def _track(handle):
+    global _open_handles
+    import atexit
+    import weakref
+
+    if _open_handles is None:
+        _open_handles = weakref.WeakSet()
+
+        def _close_all():
+            for h in list(_open_handles):
+                try:
+                    h.close()
+                except Exception:  # noqa: BLE001
+                    pass
+
+        atexit.register(_close_all)
+    _open_handles.add(handle)
+
+
 class BAHandle:
     """Resident problem: the observation lists, poses and points live in HBM between calls."""
 
@@ -123,6 +148,7 @@ class BAHandle:
         self.options = options if options is not None else default_options()
         cp, cs = prob.c_problem(), prob.c_state()
         _check(lib().mpsfm_ba_create(C.byref(cp), C.byref(cs), C.byref(self.options), C.byref(self._h)))
+        _track(self)
 
     def close(self):
         if self._h:

@@ -125,6 +125,7 @@ class HipIncrementalTriangulator:
         self._h = C.c_void_p(None)
         L.mpsfm_triangulator_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
         capi._check(L.mpsfm_triangulator_create(C.byref(g), device, C.byref(self._h)))
+        capi._track(self)  # closed before the interpreter's exit handlers give way to the C runtime's
         for name in ("triangulate_image", "complete_image"):
             getattr(L, "mpsfm_triangulator_" + name).argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
         for name in ("complete_tracks", "merge_tracks"):
